@@ -1,0 +1,281 @@
+"""Python face of the CPU oracle (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module; the product package must never do so.
+
+Two restatements of the reference's hot path live here:
+
+* the C one (oracle/qr_oracle.c -> libqroracle.so), reached through ctypes -- fast
+  enough to check mid-size cases and to serve as the timed CPU baseline;
+* `naive_*` pure-Python versions that keep the reference's own data structures
+  (dict of string keys, itertools.combinations, set of tuples) for tiny cases --
+  a second, independent witness for the C code.
+
+Parity status: PINNED against tests/golden (captured from the reference by
+tools/make_golden.py); see tests/test_oracle_golden.py.
+"""
+import ctypes
+import math
+import os
+import subprocess
+from itertools import combinations
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+c_i64p = ctypes.POINTER(ctypes.c_int64)
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+c_u32p = ctypes.POINTER(ctypes.c_uint32)
+c_u64p = ctypes.POINTER(ctypes.c_uint64)
+c_f64p = ctypes.POINTER(ctypes.c_double)
+
+
+def build():
+    """Compile oracle/qr_oracle.c with gcc (idempotent)."""
+    subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libqroracle.so")
+        if not os.path.exists(path):
+            build()
+        L = ctypes.CDLL(path)
+        L.qro_candidates.restype = ctypes.c_int64
+        L.qro_emitted_pairs.restype = ctypes.c_int64
+        L.qro_topk.restype = ctypes.c_int64
+        L.qro_free.argtypes = [ctypes.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def max_threads():
+    return int(lib().qro_max_threads())
+
+
+def set_threads(n):
+    lib().qro_set_threads(ctypes.c_int(int(n)))
+
+
+# ---------------------------------------------------------------------------
+# host-side pieces shared by every restatement
+# ---------------------------------------------------------------------------
+def legacy_permutations(seed, P, D):
+    """P consecutive np.random.permutation(D) draws from the legacy global stream
+    (recommender.py:120), made explicit: RandomState(seed) is the same stream as
+    np.random.seed(seed).  Returns int32 [P][D]."""
+    rs = np.random.RandomState(seed)
+    out = np.empty((P, D), dtype=np.int32)
+    for p in range(P):
+        out[p] = rs.permutation(D)
+    return out
+
+
+def max_candidates(nq):
+    """K = round(log_1.5 nq)  (recommender.py:151)."""
+    return round(math.log(nq, 1.5))
+
+
+def select_bands(P, thresh=0.2):
+    """Largest b with P % b == 0, b % 10 == 0 and round((1/b)**(1/r), 2) >= thresh
+    (recommender.py:153-163).  The reference falls through to an UnboundLocalError
+    when nothing qualifies; here that is a ValueError."""
+    for b in range(P, 0, -1):
+        if P % b == 0 and b % 10 == 0:
+            r = P / b
+            if round((1 / b) ** (1 / r), 2) >= thresh:
+                return b
+    raise ValueError("no band count satisfies the reference rule for PERM=%d" % P)
+
+
+# ---------------------------------------------------------------------------
+# C restatement
+# ---------------------------------------------------------------------------
+def minhash(offsets, rows, perm):
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    rows = np.ascontiguousarray(rows, dtype=np.int32)
+    perm = np.ascontiguousarray(perm, dtype=np.int32)
+    P, D = perm.shape
+    nq = len(offsets) - 1
+    sig = np.empty((nq, P), dtype=np.int32)
+    lib().qro_minhash(_p(offsets, c_i64p), _p(rows, c_i32p), ctypes.c_int64(nq), _p(perm, c_i32p),
+                      ctypes.c_int32(P), ctypes.c_int32(D), _p(sig, c_i32p))
+    return sig
+
+
+def band_keys(sig, b):
+    sig = np.ascontiguousarray(sig, dtype=np.int32)
+    nq, P = sig.shape
+    keys = np.empty((nq, b), dtype=np.uint64)
+    rc = lib().qro_band_keys(_p(sig, c_i32p), ctypes.c_int64(nq), ctypes.c_int32(P), ctypes.c_int32(b),
+                             _p(keys, c_u64p))
+    if rc != 0:
+        if P % b != 0:
+            raise AssertionError("signature length %d not divisible by b=%d" % (P, b))
+        raise ValueError("band width r=%d > 4 is not supported by the 64-bit key" % (P // b))
+    return keys
+
+
+def candidates(keys, r):
+    """-> sorted unique uint64 array of (i << 32 | j), i < j"""
+    keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    nq, b = keys.shape
+    out = c_u64p()
+    n = lib().qro_candidates(_p(keys, c_u64p), ctypes.c_int64(nq), ctypes.c_int32(b), ctypes.c_int32(r),
+                             ctypes.byref(out))
+    if n < 0:
+        raise ValueError("bad arguments")
+    arr = np.ctypeslib.as_array(out, shape=(max(n, 1),))[:n].copy()
+    lib().qro_free(out)
+    return arr
+
+
+def emitted_pairs(keys, r):
+    keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    nq, b = keys.shape
+    return int(lib().qro_emitted_pairs(_p(keys, c_u64p), ctypes.c_int64(nq), ctypes.c_int32(b),
+                                       ctypes.c_int32(r)))
+
+
+def score_pairs(sig, pairs, mode=1, want_cos=False):
+    sig = np.ascontiguousarray(sig, dtype=np.int32)
+    pairs = np.ascontiguousarray(pairs, dtype=np.uint64)
+    n = len(pairs)
+    milli = np.empty(n, dtype=np.int32)
+    cosv = np.empty(n, dtype=np.float64) if want_cos else None
+    lib().qro_score_pairs(_p(sig, c_i32p), ctypes.c_int32(sig.shape[1]), _p(pairs, c_u64p),
+                          ctypes.c_int64(n), ctypes.c_int32(mode), _p(milli, c_i32p),
+                          _p(cosv, c_f64p) if want_cos else None)
+    return (milli, cosv) if want_cos else milli
+
+
+def topk(pairs, milli, K):
+    """-> (src, dst, milli) int32 arrays, sorted by (src, value desc, dst asc), <= K per src"""
+    pairs = np.ascontiguousarray(pairs, dtype=np.uint64)
+    milli = np.ascontiguousarray(milli, dtype=np.int32)
+    n = len(pairs)
+    src = np.empty(2 * n, dtype=np.int32)
+    dst = np.empty(2 * n, dtype=np.int32)
+    val = np.empty(2 * n, dtype=np.int32)
+    m = lib().qro_topk(_p(pairs, c_u64p), _p(milli, c_i32p), ctypes.c_int64(n), ctypes.c_int32(K),
+                       _p(src, c_i32p), _p(dst, c_i32p), _p(val, c_i32p))
+    return src[:m].copy(), dst[:m].copy(), val[:m].copy()
+
+
+def query_similarities(offsets, rows, D, P, b, K, seed):
+    """Whole hot path on the CPU: -> dict with sig, keys, pairs, milli, topk arrays."""
+    perm = legacy_permutations(seed, P, D)
+    sig = minhash(offsets, rows, perm)
+    keys = band_keys(sig, b)
+    pairs = candidates(keys, P // b)
+    milli = score_pairs(sig, pairs, mode=1)
+    src, dst, val = topk(pairs, milli, K)
+    return dict(sig=sig, keys=keys, pairs=pairs, milli=milli, src=src, dst=dst, val=val)
+
+
+def sims_to_dict(src, dst, val):
+    """(src, dst, milli) COO -> {q: {'indexes': int64[], 'values': float64[]}} as
+    recommender.py:206-210 returns it (values = milli / 1000 == np.around(cos, 3))."""
+    out = {}
+    if len(src) == 0:
+        return out
+    cut = np.flatnonzero(np.diff(src)) + 1
+    starts = np.concatenate(([0], cut))
+    ends = np.concatenate((cut, [len(src)]))
+    for s, e in zip(starts, ends):
+        out[int(src[s])] = {"indexes": dst[s:e].astype(np.int64),
+                            "values": val[s:e].astype(np.float64) / 1000.0}
+    return out
+
+
+# ---------------------------------------------------------------------------
+# synthetic answer sets (bench / test input; not part of the reference)
+# ---------------------------------------------------------------------------
+def poisson_cdf_u32(mean, n=64):
+    """32-bit fixed-point CDF thresholds of Poisson(mean): size = #{k : u >= cdf[k]}."""
+    out = np.empty(n, dtype=np.uint32)
+    term = math.exp(-mean)
+    acc = 0.0
+    for k in range(n):
+        acc += term
+        out[k] = min(int(acc * 4294967296.0), 4294967295)
+        term *= mean / (k + 1)
+    return out
+
+
+def synth_csr(nq, D, seed=0, cluster=8, mean=16.0, p_replace=0.15, q0=0, nq_local=None):
+    if nq_local is None:
+        nq_local = nq - q0
+    cdf = poisson_cdf_u32(mean)
+    thr = int(p_replace * (1 << 24))
+    sizes = np.empty(nq_local, dtype=np.int32)
+    args = (ctypes.c_uint64(seed), ctypes.c_int64(q0), ctypes.c_int64(nq_local), ctypes.c_int64(nq),
+            ctypes.c_int32(cluster), ctypes.c_uint32(D), _p(cdf, c_u32p), ctypes.c_int32(len(cdf)),
+            ctypes.c_uint32(thr))
+    lib().qro_synth_sizes(*args, _p(sizes, c_i32p))
+    offsets = np.zeros(nq_local + 1, dtype=np.int64)
+    np.cumsum(sizes, out=offsets[1:])
+    rows = np.empty(int(offsets[-1]), dtype=np.int32)
+    lib().qro_synth_fill(*args, _p(offsets, c_i64p), _p(rows, c_i32p))
+    return offsets, rows
+
+
+# ---------------------------------------------------------------------------
+# naive restatement with the reference's own data structures (tiny cases only)
+# ---------------------------------------------------------------------------
+def naive_minhash(offsets, rows, perm):
+    """recommender.py:116-139 literally: walk rows in permuted order, first hit wins."""
+    P, D = perm.shape
+    nq = len(offsets) - 1
+    inv = {d: [] for d in range(D)}
+    for q in range(nq):
+        for d in rows[offsets[q]:offsets[q + 1]]:
+            inv[int(d)].append(q)
+    sign = np.full((P, nq), -1, dtype=np.int64)
+    for i in range(P):
+        p = perm[i]
+        seen = set()
+        for ind in np.argsort(p):
+            for q in inv[int(ind)]:
+                if q not in seen:
+                    seen.add(q)
+                    sign[i][q] = p[ind]
+    return sign.T
+
+
+def naive_candidates(sig, b):
+    """lsh.py:17-55 literally: int16 cast, comma-joined string keys, dict buckets,
+    combinations, set."""
+    sig = np.asarray(sig)
+    l = sig.shape[1]
+    assert l % b == 0
+    r = l // b
+    buckets = [dict() for _ in range(b)]
+    for counter, s in enumerate(sig):
+        sub = np.stack([s[i:i + r] for i in range(0, l, r)]).astype("int16").astype(str)
+        for i, sv in enumerate(sub):
+            buckets[i].setdefault(",".join(sv), []).append(counter)
+    cands = set()
+    for band in buckets:
+        for key, hits in band.items():
+            if len(hits) > 1 and set(key.split(",")) != {"-1"}:
+                for c in combinations(hits, 2):
+                    cands.add(c)
+    return cands
+
+
+def pairs_to_u64(pairs_2col):
+    a = np.asarray(pairs_2col, dtype=np.uint64).reshape(-1, 2)
+    return (a[:, 0] << np.uint64(32)) | a[:, 1]
+
+
+def u64_to_pairs(p):
+    p = np.asarray(p, dtype=np.uint64)
+    return np.stack([(p >> np.uint64(32)).astype(np.int64), (p & np.uint64(0xFFFFFFFF)).astype(np.int64)], axis=1)

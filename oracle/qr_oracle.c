@@ -1,0 +1,415 @@
+/*
+ * qr_oracle.c -- CPU restatement of the reference's MinHash-LSH hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the checker the HIP path is compared
+ * against (tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg).  Nothing
+ * in the product package (query-recommendation-system_amd/) may import, link or
+ * call it.
+ *
+ * Parity status: PINNED.  Every function below is checked against golden vectors
+ * captured from the reference's own Python code (tools/make_golden.py ->
+ * tests/golden/ (npz); tests/test_oracle_golden.py).
+ *
+ * Reference = wamuumu/query-recommendation-system @ 2025-01-14, files lsh.py and
+ * recommender.py; each function cites the lines it restates.
+ *
+ * Build: make -C oracle   (gcc -O3 -fopenmp -shared; see oracle/Makefile)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define QRO_API __attribute__((visibility("default")))
+
+QRO_API int qro_version(void) { return 1; }
+
+QRO_API int qro_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+QRO_API void qro_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
+QRO_API void qro_free(void *p) { free(p); }
+
+/* ------------------------------------------------------------------------
+ * a1. MinHash signatures -- recommender.py:105-143.
+ *
+ * The reference walks the table rows in the order of permutation p
+ * (sorted_indexes = argsort(perm), :121) and stores perm[ind] for the first row
+ * that belongs to a query (:125-129), i.e.  sig[q][p] = min_{d in A(q)} perm_p[d];
+ * a query with an empty answer set keeps the initial -1 (:116).  The result is
+ * returned transposed, one row per query (:139).
+ *
+ * perm  : [P][D] int32, perm[p] = the p-th consecutive np.random.permutation(D)
+ * A(q)  : rows[offsets[q] .. offsets[q+1])   (CSR form of compute_shingles' output)
+ * sig   : [nq][P] int32
+ * ---------------------------------------------------------------------- */
+QRO_API void qro_minhash(const int64_t *offsets, const int32_t *rows, int64_t nq,
+                         const int32_t *perm, int32_t P, int32_t D, int32_t *sig) {
+  /* row-major copy [D][P] so the inner loop over p is contiguous */
+  int32_t *pt = (int32_t *)malloc((size_t)D * (size_t)P * sizeof(int32_t));
+#pragma omp parallel for schedule(static)
+  for (int64_t d = 0; d < D; ++d)
+    for (int32_t p = 0; p < P; ++p) pt[(size_t)d * P + p] = perm[(size_t)p * D + d];
+
+#pragma omp parallel for schedule(dynamic, 256)
+  for (int64_t q = 0; q < nq; ++q) {
+    int32_t *s = sig + (size_t)q * P;
+    int64_t lo = offsets[q], hi = offsets[q + 1];
+    if (hi <= lo) {
+      for (int32_t p = 0; p < P; ++p) s[p] = -1;
+      continue;
+    }
+    const int32_t *t0 = pt + (size_t)rows[lo] * P;
+    for (int32_t p = 0; p < P; ++p) s[p] = t0[p];
+    for (int64_t k = lo + 1; k < hi; ++k) {
+      const int32_t *t = pt + (size_t)rows[k] * P;
+      for (int32_t p = 0; p < P; ++p) s[p] = t[p] < s[p] ? t[p] : s[p];
+    }
+  }
+  free(pt);
+}
+
+/* ------------------------------------------------------------------------
+ * a2. Band keys -- lsh.py:17-38.
+ *
+ * make_subvecs splits a signature into b bands of r = P / b values and casts
+ * them to int16 (:28; wraps mod 2^16).  compute_buckets joins the decimal strings
+ * with ',' (:33-34) and uses that as the dict key of band i.  Two bands get the
+ * same string iff their int16 tuples are equal, so for r <= 4 the tuple packed
+ * into 64 bits is an exact stand-in for the string:
+ *     key = sum_k (sig[band*r + k] & 0xFFFF) << (16*k)
+ * Returns 0, or -1 if P % b != 0 (the reference asserts, :20) or r > 4.
+ * keys : [nq][b] uint64
+ * ---------------------------------------------------------------------- */
+QRO_API int qro_band_keys(const int32_t *sig, int64_t nq, int32_t P, int32_t b, uint64_t *keys) {
+  if (b <= 0 || P % b != 0) return -1;
+  int32_t r = P / b;
+  if (r > 4) return -1;
+#pragma omp parallel for schedule(static)
+  for (int64_t q = 0; q < nq; ++q)
+    for (int32_t i = 0; i < b; ++i) {
+      uint64_t k = 0;
+      for (int32_t j = 0; j < r; ++j)
+        k |= (uint64_t)((uint32_t)sig[(size_t)q * P + i * r + j] & 0xFFFFu) << (16 * j);
+      keys[(size_t)q * b + i] = k;
+    }
+  return 0;
+}
+
+/* the key of a band whose r values are all int16 -1: get_candidates skips such
+ * buckets (lsh.py:45-47: keySet != {'-1'}) */
+static inline uint64_t empty_key(int32_t r) { return r >= 4 ? ~0ull : ((1ull << (16 * r)) - 1); }
+
+typedef struct { uint64_t key; uint32_t id; } rec_t;
+
+static int cmp_rec(const void *a, const void *b) {
+  const rec_t *x = (const rec_t *)a, *y = (const rec_t *)b;
+  if (x->key != y->key) return x->key < y->key ? -1 : 1;
+  return x->id < y->id ? -1 : (x->id > y->id);
+}
+static int cmp_u64(const void *a, const void *b) {
+  uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+  return x < y ? -1 : (x > y);
+}
+
+/* LSD radix sort of 64-bit words (used so the CPU baseline is not a qsort strawman) */
+static void radix_sort_u64(uint64_t *a, int64_t n) {
+  if (n < 2) return;
+  uint64_t *tmp = (uint64_t *)malloc((size_t)n * sizeof(uint64_t));
+  uint64_t *src = a, *dst = tmp;
+  uint64_t orall = 0, andall = ~0ull;
+  for (int64_t i = 0; i < n; ++i) { orall |= a[i]; andall &= a[i]; }
+  uint64_t diff = orall ^ andall;
+  for (int shift = 0; shift < 64; shift += 8) {
+    if (((diff >> shift) & 0xFF) == 0) continue;
+    int64_t cnt[257] = {0};
+    for (int64_t i = 0; i < n; ++i) cnt[((src[i] >> shift) & 0xFF) + 1]++;
+    for (int d = 0; d < 256; ++d) cnt[d + 1] += cnt[d];
+    for (int64_t i = 0; i < n; ++i) dst[cnt[(src[i] >> shift) & 0xFF]++] = src[i];
+    uint64_t *t = src; src = dst; dst = t;
+  }
+  if (src != a) memcpy(a, src, (size_t)n * sizeof(uint64_t));
+  free(tmp);
+}
+
+/* ------------------------------------------------------------------------
+ * a3. Candidate pairs -- lsh.py:40-55.
+ *
+ * For every band, every bucket with more than one member whose key is not the
+ * all -1 tuple contributes all combinations(hits, 2) (:47-49); hits are in
+ * insertion (= query id) order so each pair is (i, j) with i < j; the Python set
+ * removes duplicates across bands (:41, :53).  The `reversed(c) in candidates`
+ * test (:52) compares an iterator object and is always False.
+ *
+ * Output: *pairs_out = malloc'ed sorted unique array of (i << 32 | j); returns the
+ * count, or -1 on bad arguments.  Free with qro_free.
+ * ---------------------------------------------------------------------- */
+QRO_API int64_t qro_candidates(const uint64_t *keys, int64_t nq, int32_t b, int32_t r,
+                               uint64_t **pairs_out) {
+  *pairs_out = NULL;
+  if (nq < 0 || b <= 0 || r <= 0 || r > 4) return -1;
+  const uint64_t ek = empty_key(r);
+  int nthreads = qro_max_threads();
+  uint64_t **tp = (uint64_t **)calloc((size_t)nthreads, sizeof(uint64_t *));
+  int64_t *tn = (int64_t *)calloc((size_t)nthreads, sizeof(int64_t));
+  int64_t *tc = (int64_t *)calloc((size_t)nthreads, sizeof(int64_t));
+
+#pragma omp parallel
+  {
+#ifdef _OPENMP
+    int tid = omp_get_thread_num();
+#else
+    int tid = 0;
+#endif
+    rec_t *rec = (rec_t *)malloc((size_t)(nq > 0 ? nq : 1) * sizeof(rec_t));
+#pragma omp for schedule(dynamic, 1)
+    for (int32_t band = 0; band < b; ++band) {
+      for (int64_t q = 0; q < nq; ++q) {
+        rec[q].key = keys[(size_t)q * b + band];
+        rec[q].id = (uint32_t)q;
+      }
+      qsort(rec, (size_t)nq, sizeof(rec_t), cmp_rec);
+      int64_t s = 0;
+      while (s < nq) {
+        int64_t e = s + 1;
+        while (e < nq && rec[e].key == rec[s].key) ++e;
+        int64_t m = e - s;
+        if (m > 1 && rec[s].key != ek) {
+          int64_t need = tn[tid] + m * (m - 1) / 2;
+          if (need > tc[tid]) {
+            int64_t nc = tc[tid] ? tc[tid] : 1024;
+            while (nc < need) nc *= 2;
+            tp[tid] = (uint64_t *)realloc(tp[tid], (size_t)nc * sizeof(uint64_t));
+            tc[tid] = nc;
+          }
+          for (int64_t x = s; x < e; ++x)
+            for (int64_t y = x + 1; y < e; ++y)
+              tp[tid][tn[tid]++] = ((uint64_t)rec[x].id << 32) | rec[y].id;
+        }
+        s = e;
+      }
+    }
+    free(rec);
+  }
+  int64_t total = 0;
+  for (int t = 0; t < nthreads; ++t) total += tn[t];
+  uint64_t *all = (uint64_t *)malloc((size_t)(total > 0 ? total : 1) * sizeof(uint64_t));
+  int64_t o = 0;
+  for (int t = 0; t < nthreads; ++t) {
+    if (tn[t]) memcpy(all + o, tp[t], (size_t)tn[t] * sizeof(uint64_t));
+    o += tn[t];
+    free(tp[t]);
+  }
+  free(tp); free(tn); free(tc);
+  radix_sort_u64(all, total);
+  int64_t u = 0;
+  for (int64_t i = 0; i < total; ++i)
+    if (i == 0 || all[i] != all[i - 1]) all[u++] = all[i];
+  *pairs_out = all;
+  return u;
+}
+
+/* number of pairs before cross-band de-duplication (what the per-band
+ * combinations() loops generate in total, lsh.py:49) */
+QRO_API int64_t qro_emitted_pairs(const uint64_t *keys, int64_t nq, int32_t b, int32_t r) {
+  if (nq <= 0 || b <= 0 || r <= 0 || r > 4) return 0;
+  const uint64_t ek = empty_key(r);
+  int64_t total = 0;
+  uint64_t *col = (uint64_t *)malloc((size_t)nq * sizeof(uint64_t));
+  for (int32_t band = 0; band < b; ++band) {
+    for (int64_t q = 0; q < nq; ++q) col[q] = keys[(size_t)q * b + band];
+    qsort(col, (size_t)nq, sizeof(uint64_t), cmp_u64);
+    int64_t s = 0;
+    while (s < nq) {
+      int64_t e = s + 1;
+      while (e < nq && col[e] == col[s]) ++e;
+      if (col[s] != ek) total += (e - s) * (e - s - 1) / 2;
+      s = e;
+    }
+  }
+  free(col);
+  return total;
+}
+
+/* ------------------------------------------------------------------------
+ * a5 (first half). Pair scoring -- recommender.py:203-204.
+ *
+ *   values = np.around(cosine_similarity([sig_i, sig_j1, ...])[0][1:], 3)
+ *
+ * sklearn's cosine_similarity L2-normalises each row in float64 (a zero row is
+ * left as zeros) and multiplies the normalised rows.  np.around(x, 3) is
+ * rint(x * 1000) / 1000.
+ *
+ * mode 0 ("sklearn order"): normalise, then sum of products of the normalised
+ *         entries -- the reference's arithmetic up to BLAS summation order.
+ * mode 1 ("exact"): integer dot and squared norms (exact in int64), then
+ *         dot / (sqrt(na) * sqrt(nb)) -- what the HIP kernel computes.
+ * The two differ by a few ulp before rounding and are checked equal after it
+ * (tests/test_oracle_golden.py) on every golden pair.
+ *
+ * milli[n] = (int) rint(cos * 1000);  cosv[n] (optional) = the unrounded cosine.
+ * ---------------------------------------------------------------------- */
+QRO_API void qro_score_pairs(const int32_t *sig, int32_t P, const uint64_t *pairs, int64_t n,
+                             int32_t mode, int32_t *milli, double *cosv) {
+#pragma omp parallel for schedule(static)
+  for (int64_t t = 0; t < n; ++t) {
+    const int32_t *a = sig + (size_t)(pairs[t] >> 32) * P;
+    const int32_t *c = sig + (size_t)(pairs[t] & 0xFFFFFFFFu) * P;
+    int64_t dot = 0, na = 0, nb = 0;
+    for (int32_t p = 0; p < P; ++p) {
+      dot += (int64_t)a[p] * c[p];
+      na += (int64_t)a[p] * a[p];
+      nb += (int64_t)c[p] * c[p];
+    }
+    double cs;
+    if (na == 0 || nb == 0) {
+      cs = 0.0;
+    } else if (mode == 0) {
+      double ia = sqrt((double)na), ib = sqrt((double)nb), acc = 0.0;
+      for (int32_t p = 0; p < P; ++p) acc += ((double)a[p] / ia) * ((double)c[p] / ib);
+      cs = acc;
+    } else {
+      cs = (double)dot / (sqrt((double)na) * sqrt((double)nb));
+    }
+    milli[t] = (int32_t)rint(cs * 1000.0);
+    if (cosv) cosv[t] = cs;
+  }
+}
+
+/* ------------------------------------------------------------------------
+ * a5 (second half). Per-query top-K -- recommender.py:185-210.
+ *
+ * Every candidate pair (i, j) makes j a neighbour of i and i a neighbour of j
+ * (:198-199).  Per query the neighbours are ordered by rounded value, descending,
+ * and the first K kept (:206).  The reference's order among equal values is
+ * whatever np.argsort and Python set iteration produce (arbitrary); this
+ * restatement fixes it: value descending, then neighbour id ascending.
+ *
+ * Output (caller allocates 2*n each): directed edges sorted by (src, value desc,
+ * dst asc), at most K per src.  Returns the number of edges kept.
+ * ---------------------------------------------------------------------- */
+typedef struct { uint64_t hi, lo; } k2_t;
+static int cmp_k2(const void *a, const void *b) {
+  const k2_t *x = (const k2_t *)a, *y = (const k2_t *)b;
+  if (x->hi != y->hi) return x->hi < y->hi ? -1 : 1;
+  return x->lo < y->lo ? -1 : (x->lo > y->lo);
+}
+
+QRO_API int64_t qro_topk(const uint64_t *pairs, const int32_t *milli, int64_t n, int32_t K,
+                         int32_t *src, int32_t *dst, int32_t *val) {
+  /* sortable 16-byte records: hi = src << 32 | (2000 - (milli + 1000)), lo = dst */
+  k2_t *k = (k2_t *)malloc((size_t)(n > 0 ? 2 * n : 1) * sizeof(k2_t));
+  for (int64_t t = 0; t < n; ++t) {
+    uint32_t i = (uint32_t)(pairs[t] >> 32), j = (uint32_t)(pairs[t] & 0xFFFFFFFFu);
+    uint32_t inv = (uint32_t)(1000 - milli[t]); /* milli in [-1000, 1000] -> inv in [0, 2000] */
+    k[2 * t].hi = ((uint64_t)i << 32) | inv; k[2 * t].lo = j;
+    k[2 * t + 1].hi = ((uint64_t)j << 32) | inv; k[2 * t + 1].lo = i;
+  }
+  qsort(k, (size_t)(2 * n), sizeof(k2_t), cmp_k2);
+  int64_t out = 0, run = 0;
+  uint32_t cur = 0;
+  for (int64_t t = 0; t < 2 * n; ++t) {
+    uint32_t s = (uint32_t)(k[t].hi >> 32);
+    if (t == 0 || s != cur) { cur = s; run = 0; }
+    if (run < K) {
+      src[out] = (int32_t)s;
+      dst[out] = (int32_t)k[t].lo;
+      val[out] = 1000 - (int32_t)(uint32_t)(k[t].hi & 0xFFFFFFFFu);
+      ++out;
+    }
+    ++run;
+  }
+  free(k);
+  return out;
+}
+
+/* ------------------------------------------------------------------------
+ * Synthetic answer sets: a pure function of (seed, q) so
+ * the CPU, the GPU and every shard regenerate identical rows.  Not part of the
+ * reference; bench / test input only.  The HIP twin is qrlsh_synth_* and must be
+ * bit-identical (tests/test_gpu_parity.py).
+ *
+ *   nb      = max(1, nq / cluster) base sets
+ *   |base|  = clamp(Poisson(mean) via the caller's 32-bit CDF table, 1, 48)
+ *   base[k] = uniform in [0, D)
+ *   query q = base (q mod nb) with each element independently replaced by a
+ *             uniform draw when a 24-bit draw < rep_thresh24; then sort-unique
+ * ---------------------------------------------------------------------- */
+#define QRO_MAXS 48
+
+static inline uint64_t mix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+static inline uint64_t rnd(uint64_t seed, uint64_t stream, uint64_t idx, uint64_t ctr) {
+  uint64_t x = seed + 0x9E3779B97F4A7C15ull * (stream + 1);
+  x = mix64(x ^ (idx * 0xD1342543DE82EF95ull));
+  x = mix64(x + ctr * 0xA24BAED4963EE407ull + 0x9E3779B97F4A7C15ull);
+  return x;
+}
+static inline uint32_t to_range(uint64_t r, uint32_t D) {
+  return (uint32_t)(((r >> 32) * (uint64_t)D) >> 32);
+}
+
+static int synth_one(uint64_t seed, int64_t q, int64_t nb, uint32_t D, const uint32_t *cdf,
+                     int32_t ncdf, uint32_t rep_thresh24, uint32_t *out) {
+  uint64_t bidx = (uint64_t)(q % nb);
+  uint32_t u = (uint32_t)(rnd(seed, 1, bidx, 0) >> 32);
+  int32_t size = 0;
+  while (size < ncdf && u >= cdf[size]) ++size;
+  if (size < 1) size = 1;
+  if (size > QRO_MAXS) size = QRO_MAXS;
+  int n = 0;
+  for (int32_t k = 0; k < size; ++k) {
+    uint32_t e = to_range(rnd(seed, 2, bidx, (uint64_t)k), D);
+    uint64_t rr = rnd(seed, 3, (uint64_t)q, (uint64_t)k);
+    if ((uint32_t)(rr & 0xFFFFFFu) < rep_thresh24) e = to_range(rnd(seed, 4, (uint64_t)q, (uint64_t)k), D);
+    /* insertion into sorted unique list */
+    int pos = n;
+    while (pos > 0 && out[pos - 1] > e) --pos;
+    if (pos > 0 && out[pos - 1] == e) continue;
+    for (int m = n; m > pos; --m) out[m] = out[m - 1];
+    out[pos] = e;
+    ++n;
+  }
+  return n;
+}
+
+QRO_API void qro_synth_sizes(uint64_t seed, int64_t q0, int64_t nq_local, int64_t nq_total,
+                             int32_t cluster, uint32_t D, const uint32_t *cdf, int32_t ncdf,
+                             uint32_t rep_thresh24, int32_t *sizes) {
+  int64_t nb = nq_total / cluster; if (nb < 1) nb = 1;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < nq_local; ++i) {
+    uint32_t tmp[QRO_MAXS];
+    sizes[i] = synth_one(seed, q0 + i, nb, D, cdf, ncdf, rep_thresh24, tmp);
+  }
+}
+
+QRO_API void qro_synth_fill(uint64_t seed, int64_t q0, int64_t nq_local, int64_t nq_total,
+                            int32_t cluster, uint32_t D, const uint32_t *cdf, int32_t ncdf,
+                            uint32_t rep_thresh24, const int64_t *offsets, int32_t *rows) {
+  int64_t nb = nq_total / cluster; if (nb < 1) nb = 1;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < nq_local; ++i) {
+    uint32_t tmp[QRO_MAXS];
+    int n = synth_one(seed, q0 + i, nb, D, cdf, ncdf, rep_thresh24, tmp);
+    for (int k = 0; k < n; ++k) rows[offsets[i] + k] = (int32_t)tmp[k];
+  }
+}

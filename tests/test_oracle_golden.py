@@ -1,0 +1,106 @@
+"""CPU tests: the oracle (oracle/) against golden vectors captured from the reference
+(tools/make_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from helpers import FULL, PIECES, load, pairs_u64, check_topk_tie_aware
+
+
+@pytest.mark.parametrize("name", FULL + PIECES)
+def test_minhash_matches_reference(name):
+    g = load(name)
+    perm = O.legacy_permutations(int(g["seed"]), int(g["P"]), int(g["D"]))
+    sig = O.minhash(g["offsets"], g["rows"], perm)
+    assert sig.dtype == np.int32
+    assert np.array_equal(sig, g["sig"])
+
+
+@pytest.mark.parametrize("name", ["cfg1_hotpath", "full_p160_ties"])
+def test_naive_minhash_matches_reference(name):
+    g = load(name)
+    perm = O.legacy_permutations(int(g["seed"]), int(g["P"]), int(g["D"]))
+    sig = O.naive_minhash(g["offsets"], g["rows"], perm)
+    assert np.array_equal(sig, g["sig"])
+
+
+@pytest.mark.parametrize("name", FULL + PIECES)
+def test_candidates_match_reference(name):
+    g = load(name)
+    P, b = int(g["P"]), int(g["b"])
+    keys = O.band_keys(g["sig"], b)
+    pairs = O.candidates(keys, P // b)
+    assert np.array_equal(pairs, np.sort(pairs_u64(g["pairs"])))
+    assert O.emitted_pairs(keys, P // b) >= len(pairs)
+
+
+def test_lsh_edge_semantics():
+    g = load("lsh_edge")
+    sig = g["sig"]
+    b = int(g["b"])
+    # int16 wrap happens on the low 16 bits; feed the oracle the wrapped int32 view
+    sig32 = (sig & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
+    keys = O.band_keys(sig32, b)
+    pairs = O.candidates(keys, sig.shape[1] // b)
+    assert np.array_equal(pairs, np.sort(pairs_u64(g["pairs"])))
+    naive = O.naive_candidates(sig, b)
+    assert sorted(naive) == [tuple(x) for x in g["pairs"].tolist()]
+    assert bool(g["assert_raised"])
+    with pytest.raises(AssertionError):
+        O.band_keys(sig32, 5)
+    # make_subvecs view of row 2 (int16 wrap of +65536)
+    r = sig.shape[1] // b
+    assert np.array_equal(g["subvecs_row2"], sig[2].reshape(b, r).astype(np.int16))
+
+
+@pytest.mark.parametrize("name", ["cfg1_hotpath", "pieces_p128_b32_wrap"])
+def test_naive_candidates_match_reference(name):
+    g = load(name)
+    naive = O.naive_candidates(g["sig"], int(g["b"]))
+    assert sorted(naive) == [tuple(x) for x in g["pairs"].tolist()]
+
+
+@pytest.mark.parametrize("name", FULL + PIECES)
+def test_scores_match_sklearn_rounding(name):
+    g = load(name)
+    pairs = np.sort(pairs_u64(g["pairs"]))
+    # golden pair_cos is in the order of g["pairs"], which is already sorted
+    assert np.array_equal(pairs, pairs_u64(g["pairs"]))
+    m_exact = O.score_pairs(g["sig"], pairs, mode=1)
+    m_skl = O.score_pairs(g["sig"], pairs, mode=0)
+    assert np.array_equal(m_exact, m_skl)
+    assert np.array_equal(m_exact / 1000.0, g["pair_cos"])
+
+
+@pytest.mark.parametrize("name", FULL)
+def test_topk_matches_reference_tie_aware(name):
+    g = load(name)
+    P, b, K = int(g["P"]), int(g["b"]), int(g["K"])
+    r = O.query_similarities(g["offsets"], g["rows"], int(g["D"]), P, b, K, int(g["seed"]))
+    check_topk_tie_aware(g, r["pairs"], r["milli"], r["src"], r["dst"], r["val"], K)
+    d = O.sims_to_dict(r["src"], r["dst"], r["val"])
+    assert sorted(d.keys()) == sorted(int(q) for q in g["qs_q"])
+
+
+def test_band_rule_matches_reference_choices():
+    # values observed from the reference run (golden 'b' and 'K')
+    for name in FULL:
+        g = load(name)
+        assert O.select_bands(int(g["P"])) == int(g["b"])
+        nq = len(g["offsets"]) - 1
+        assert O.max_candidates(nq) == int(g["K"])
+    for P in (128, 256):
+        with pytest.raises(ValueError):
+            O.select_bands(P)
+
+
+def test_synth_generator_is_a_pure_function_of_index():
+    off, rows = O.synth_csr(4000, 32768, seed=0)
+    off2, rows2 = O.synth_csr(4000, 32768, seed=0, q0=1000, nq_local=500)
+    assert np.array_equal(rows[off[1000]:off[1500]], rows2)
+    sizes = np.diff(off)
+    assert sizes.min() >= 1 and sizes.max() <= 48
+    assert 14.0 < sizes.mean() < 18.0
+    for q in (0, 17, 3999):
+        s = rows[off[q]:off[q + 1]]
+        assert np.all(np.diff(s) > 0) and s.min() >= 0 and s.max() < 32768
