@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path of SURVEY.md section 8 on synthetic answer sets, on N GPUs of one node.
+
+A step = one pass of the whole hot path (MinHash signatures + band keys -> bucket sort ->
+pair emit -> sort/unique -> pair scoring -> per-query top-K) over one batch of queries whose
+CSR answer sets and permutation table are already resident in HBM.
+
+Workload at N=1: BASELINE.json configs[1] -- 1 M queries x 128-perm MinHash, 32 bands
+(D = 32768 table rows, mean answer-set size 16, clusters of 8; K = round(log_1.5 nq) = 34).
+For N > 1 every rank owns 1 M queries of an N x 1 M problem (weak scaling): signatures are
+computed per shard, band keys are all-gathered over RCCL, bands are split across ranks for
+the bucket sort, emitted pairs are exchanged to their owner (all-to-all), and owners score.
+
+Prints ONE JSON line on rank 0 (contract in the task statement).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "query-recommendation-system_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--nq", type=int, default=1_000_000, help="queries per GPU")
+    ap.add_argument("--perm", type=int, default=128)
+    ap.add_argument("--bands", type=int, default=32)
+    ap.add_argument("--drows", type=int, default=32768)
+    ap.add_argument("--cpu-sample", type=int, default=100_000, help="queries in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
+    return ap.parse_args()
+
+
+def algorithmic_bytes(label, w):
+    """Algorithmic HBM bytes of ONE launch of a kernel label on workload w (SURVEY.md 8d;
+    int32 signatures, uint64 keys, 8-byte pairs).  Returns (bytes, unit description)."""
+    nq, P, b, nnz = w["nq"], w["P"], w["b"], w["nnz"]
+    if label == "minhash":
+        # read CSR (4 B/row id + 8 B offset), write sig (4P) + fused band keys (8b) + norm (8)
+        return 4 * nnz + 8 * nq + (4 * P + 8 * b + 8) * nq
+    if label == "sort_hist":
+        return None  # depends on which sort; filled by caller
+    if label == "score_pairs":
+        return (8 * P + 16) * w["unique_pairs"]
+    return None
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (WORLD_SIZE=%d)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import qrlsh
+    from qrlsh import ops, pipeline, _lib
+    _lib.load()  # fails loudly if the HIP extension is missing
+
+    nq_local, P, b, D = args.nq, args.perm, args.bands, args.drows
+    nq_total = nq_local * world
+    K = pipeline.max_candidates(nq_total)
+    q0 = rank * nq_local
+    off, rows = qrlsh.synth_csr(nq_total, D, seed=0, q0=q0, nq_local=nq_local, device=dev)
+    perms = ops.legacy_permutations(P, D, seed=42)
+    table = ops.perm_table(perms, dev)
+    nnz = int(rows.numel())
+
+    if world == 1:
+        def step():
+            return pipeline.query_similarities(off, rows, table, b, K)
+    else:
+        from qrlsh import dist as qdist
+
+        def step():
+            return qdist.query_similarities_sharded(off, rows, table, b, K, nq_total)
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    res = None
+    for _ in range(args.warmup):
+        res = step()
+    sync()
+    if not args.no_prof:
+        _lib.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    prof = {}
+    if not args.no_prof:
+        prof = _lib.prof_report()
+        _lib.prof_enable(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        cnt = torch.tensor([res.pairs.numel(), res.stats.get("emitted_pairs", 0)], dtype=torch.int64, device=dev)
+        dist.all_reduce(cnt)
+        unique_pairs, emitted = int(cnt[0].item()), int(cnt[1].item())
+    else:
+        unique_pairs, emitted = int(res.pairs.numel()), int(res.stats.get("emitted_pairs", 0))
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = nq_total * args.steps / elapsed
+
+    out = None
+    if rank == 0:
+        w = dict(nq=nq_local, P=P, b=b, nnz=nnz, unique_pairs=int(res.pairs.numel()))
+        kernels = {}
+        for name, (cnt_, ms) in prof.items():
+            kernels[name] = {"launches_per_step": cnt_ / args.steps, "ms_per_step": ms / args.steps,
+                             "avg_ms": ms / cnt_}
+        roofline = None
+        if kernels:
+            dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+            # records moved by one launch of each sort kernel in the bucket sort (the big one): b*nq
+            per_launch = {
+                "minhash": algorithmic_bytes("minhash", w),
+                "score_pairs": algorithmic_bytes("score_pairs", w),
+                # bucket sort dominates the sort_* labels: (key 8 + id 4) read + write per record
+                "sort_scatter_kv": 24 * b * nq_local * (world if world > 1 else 1) // max(world, 1),
+                "sort_hist": None,
+                "sort_scatter_k": None,
+            }
+            ab = per_launch.get(dom)
+            avg_ms = kernels[dom]["avg_ms"]
+            if ab is not None:
+                achieved = ab / (avg_ms * 1e-3) / 1e9
+                roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                            "algorithmic_bytes_per_launch": ab, "avg_launch_ms": round(avg_ms, 4),
+                            "launches_per_step": kernels[dom]["launches_per_step"]}
+            else:
+                roofline = {"kernel": dom, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": None, "traffic": None, "avg_launch_ms": round(avg_ms, 4),
+                            "launches_per_step": kernels[dom]["launches_per_step"]}
+            # per-kernel achieved GB/s for the kernels with a closed-form byte count
+            for kname in ("minhash", "score_pairs", "sort_scatter_kv"):
+                if kname in kernels and per_launch.get(kname):
+                    kernels[kname]["algorithmic_GBps"] = round(per_launch[kname] / (kernels[kname]["avg_ms"] * 1e-3) / 1e9, 1)
+
+        cpu_baseline = None
+        recall = None
+        if args.cpu_sample > 0:
+            cpu_baseline, recall = cpu_leg(args.cpu_sample, D, P, b, dev)
+
+        out = {
+            "metric": "MinHash signatures/sec through the whole hot path (signatures -> LSH candidates -> pair scoring -> top-K)",
+            "value": round(value, 1),
+            "unit": "signatures/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int32 signatures / uint64 keys (integer); float64 cosine",
+            "data": "synthetic (clustered answer sets, SURVEY 8d recipe; seed 0; permutation seed 42)",
+            "config": {"workload": "configs[1]: %d queries/GPU x %d-perm MinHash, %d bands, D=%d, K=%d, mean |A(q)|=%.2f"
+                       % (nq_local, P, b, D, K, nnz / nq_local),
+                       "queries_total": nq_total, "parallelism": "query-sharded x%d" % world},
+            "pairs_scored_per_sec": round(unique_pairs * args.steps / elapsed, 1),
+            "unique_pairs": unique_pairs,
+            "emitted_pairs": emitted,
+            "recall_at_10": recall,
+            "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()}
+                        for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])},
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+        }
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out))
+
+
+def cpu_leg(nq_s, D, P, b, dev):
+    """CPU baseline (oracle = a C port of the reference's algorithm, OpenMP) on a bounded
+    sample of the same workload, and recall@10 of the GPU path against it."""
+    import qrlsh
+    from qrlsh import ops, pipeline
+    from oracle import oracle as O  # the checker / CPU baseline; never on the measured GPU path
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import recall_at_k
+
+    K = pipeline.max_candidates(nq_s)
+    perms = ops.legacy_permutations(P, D, seed=42)
+    ho, hr = O.synth_csr(nq_s, D, seed=0)
+    cores = O.max_threads()
+    O.query_similarities(ho[:2001], hr[:ho[2000]], D, P, b, K, 42)  # warm the library / threads
+    t0 = time.perf_counter()
+    sig = O.minhash(ho, hr, perms)
+    t1 = time.perf_counter()
+    keys = O.band_keys(sig, b)
+    pairs = O.candidates(keys, P // b)
+    t2 = time.perf_counter()
+    milli = O.score_pairs(sig, pairs, mode=1)
+    s, d, v = O.topk(pairs, milli, K)
+    t3 = time.perf_counter()
+    off = torch.from_numpy(ho).to(dev)
+    rows = torch.from_numpy(hr).to(dev)
+    res = pipeline.query_similarities(off, rows, ops.perm_table(perms, dev), b, K)
+    torch.cuda.synchronize()
+    exact = bool(np.array_equal(res.sig.cpu().numpy(), sig)
+                 and np.array_equal(res.pairs.cpu().numpy().view(np.uint64), pairs)
+                 and np.array_equal(res.milli.cpu().numpy(), milli))
+    recall = recall_at_k(s, d, v, res.src.cpu().numpy(), res.dst.cpu().numpy(), res.val.cpu().numpy(), 10)
+    total = t3 - t0
+    base = {
+        "value": round(nq_s / total, 1), "unit": "signatures/s", "cores": cores, "kind": "port",
+        "sample": "whole hot path on nq=%d queries of the same synthetic recipe (P=%d, b=%d, D=%d), oracle/qr_oracle.c with OpenMP, %d threads"
+                  % (nq_s, P, b, D, cores),
+        "seconds": round(total, 3),
+        "phases_s": {"signatures": round(t1 - t0, 3), "candidates": round(t2 - t1, 3), "scoring_topk": round(t3 - t2, 3)},
+        "minhash_signatures_per_s": round(nq_s / (t1 - t0), 1),
+        "pairs_scored_per_s": round(len(pairs) / max(t3 - t2, 1e-9), 1),
+        "gpu_bit_exact_on_sample": exact,
+    }
+    return base, round(recall, 6)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,160 @@
+/*
+ * qrlsh.h -- C ABI of libqrlsh.so, the MI355X (gfx950) implementation of the
+ * MinHash-LSH candidate-generation + pair-scoring hot path of
+ * wamuumu/query-recommendation-system (lsh.py, recommender.py:105-214).
+ *
+ * The reference is pure Python and has no FFI of its own; this header is the
+ * boundary its Python call surface (lsh.LSH, Recommender.compute_signatures /
+ * compute_querySimilarities) binds through ctypes.  INTEGRATION.md shows the
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the parameter name ends in _host;
+ *   - the caller owns every buffer (torch tensors in the Python host layer); the
+ *     library never allocates device memory;
+ *   - variable-size outputs are count-then-fill: *_count leaves the size in a
+ *     device word the caller reads back, *_fill writes into caller memory;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all calls
+ *     are asynchronous on it and safe under hipGraph capture (no allocation, no sync);
+ *   - return value: 0 (QRLSH_OK) or a negative QRLSH_E* code; qrlsh_last_error()
+ *     gives a thread-local message for the last failure on this thread.
+ */
+#ifndef QRLSH_H
+#define QRLSH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QRLSH_OK 0
+#define QRLSH_EINVAL (-1)       /* bad argument (incl. P % b != 0: lsh.py:20 asserts) */
+#define QRLSH_EHIP (-2)         /* a HIP runtime call failed */
+#define QRLSH_EUNSUPPORTED (-3) /* shape outside what the kernels cover (e.g. r > 4) */
+#define QRLSH_EWORKSPACE (-4)   /* workspace too small */
+
+#define QRLSH_PERM_U16 0 /* permutation table element = uint16 (D <= 65536) */
+#define QRLSH_PERM_I32 1 /* permutation table element = int32 */
+
+#define QRLSH_SORT_MIX 1u  /* radix digits are taken from mix64(key) (grouping sort) */
+#define QRLSH_SORT_IOTA 2u /* first pass synthesises vals = index within the batch */
+
+int qrlsh_version(void);
+const char *qrlsh_last_error(void);
+
+/* 64-bit bijective mixer used by QRLSH_SORT_MIX (host copy, for tests) */
+uint64_t qrlsh_mix64_host(uint64_t x);
+
+/* ---- a1: MinHash signatures ------------------------------------------------
+ * Replaces Recommender.compute_signatures, recommender.py:105-143:
+ *     sig[q][p] = min_{d in A(q)} perm_p[d],  -1 when A(q) is empty.
+ * offsets[nq+1] / rows[nnz] : CSR answer sets (compute_shingles' output, :68-103)
+ * perm_t : the P permutations TRANSPOSED, [D][P_stride] (row d = the P permuted
+ *          indices of table row d), element type perm_dtype; P_stride >= P, and
+ *          P_stride * sizeof(element) a multiple of 16.
+ * sig_out   [nq][P] int32 (row-major; the reference returns the same matrix as int64)
+ * norm2_out [nq] int64 = sum_p sig^2 (exact), or NULL          -- feeds qrlsh_score_pairs
+ * keys_out  [b][nq] uint64 band keys (see qrlsh_band_keys), or NULL -- fused a2
+ */
+int qrlsh_minhash(const int64_t *offsets, const int32_t *rows, int64_t nq, const void *perm_t,
+                  int32_t perm_dtype, int32_t P, int32_t P_stride, int32_t D, int32_t *sig_out,
+                  int64_t *norm2_out, uint64_t *keys_out, int32_t b, void *stream);
+
+/* ---- a2: band keys -----------------------------------------------------------
+ * Replaces LSH.make_subvecs / compute_buckets' key construction, lsh.py:17-38:
+ * band i of a signature = its values [i*r, (i+1)*r) cast to int16 (:28) and joined
+ * into a string (:33).  Equal strings <=> equal int16 tuples, so for r <= 4
+ *     key = sum_k (sig[i*r + k] & 0xFFFF) << (16 * k)
+ * is an exact bucket id.  keys_out is band-major [b][nq].  norm2_out optional.
+ * Returns QRLSH_EINVAL if P % b != 0, QRLSH_EUNSUPPORTED if r > 4.
+ */
+int qrlsh_band_keys(const int32_t *sig, int64_t nq, int32_t P, int32_t b, uint64_t *keys_out,
+                    int64_t *norm2_out, void *stream);
+
+/* ---- radix sort (replaces the dict-of-lists buckets, lsh.py:9-15,31-38) -------
+ * Stable LSD radix sort of nbatch independent arrays of n uint64 keys (+ optional
+ * uint32 payload), 8 bits per pass over bits [bit_lo, bit_hi) of the key (or of
+ * mix64(key) with QRLSH_SORT_MIX: equal keys still end up adjacent, in payload
+ * order, after 32 bits instead of 64).  Buffers a/b ping-pong; the return value
+ * (>= 0) says where the result is: 0 = a, 1 = b.  vals_a/vals_b may both be NULL.
+ */
+size_t qrlsh_sort_workspace_bytes(int64_t n, int32_t nbatch);
+int qrlsh_sort_u64(uint64_t *keys_a, uint64_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, int64_t n,
+                   int32_t nbatch, int32_t bit_lo, int32_t bit_hi, uint32_t flags, void *workspace,
+                   size_t workspace_bytes, void *stream);
+
+/* ---- a3: candidate pairs -------------------------------------------------------
+ * Replaces LSH.get_candidates, lsh.py:40-55.  Input: per band, keys sorted with
+ * QRLSH_SORT_MIX over 32 bits and their query ids ([b][nq] each).  Every run of
+ * equal keys that is not the all -1 tuple (:47) yields all its (i < j) pairs (:49).
+ * pairs are i << 32 | j; duplicates across bands are still present (the Python
+ * set's job, :41) -- sort them and call qrlsh_unique_*.
+ *   count: *total_out (device uint64) = number of pairs; workspace keeps per-block offsets
+ *   fill : writes exactly that many pairs (capacity checked by the caller)
+ */
+size_t qrlsh_pairs_workspace_bytes(int64_t nq, int32_t b);
+int qrlsh_pairs_count(const uint64_t *sorted_keys, int64_t nq, int32_t b, int32_t r, void *workspace,
+                      size_t workspace_bytes, uint64_t *total_out, void *stream);
+int qrlsh_pairs_fill(const uint64_t *sorted_keys, const uint32_t *sorted_ids, int64_t nq, int32_t b,
+                     int32_t r, const void *workspace, uint64_t *pairs_out, void *stream);
+
+/* unique of a sorted uint64 array (count-then-fill) */
+size_t qrlsh_compact_workspace_bytes(int64_t n);
+int qrlsh_unique_count(const uint64_t *sorted, int64_t n, void *workspace, size_t workspace_bytes,
+                       uint64_t *total_out, void *stream);
+int qrlsh_unique_fill(const uint64_t *sorted, int64_t n, const void *workspace, uint64_t *out,
+                      void *stream);
+
+/* ---- a5: pair scoring ------------------------------------------------------------
+ * Replaces the cosine of recommender.py:203-204 for one candidate pair:
+ *     np.around(cosine_similarity([sig_i, sig_j])[0][1], 3)
+ * computed as exact integer dot / (sqrt(norm2_i) * sqrt(norm2_j)) in float64 (0 if a
+ * norm is 0, as sklearn's normalize does), milli = rint(cos * 1000) so that
+ * milli / 1000.0 == np.around(cos, 3).
+ * cos_out (double, unrounded) and edge_out are optional.  edge_out[2n] receives the two
+ * directed top-K sort keys of each pair:
+ *     src << (id_bits + 11) | (1000 - milli) << id_bits | dst        (needs id_bits <= 26)
+ */
+int qrlsh_row_norms(const int32_t *sig, int64_t nq, int32_t P, int64_t *norm2_out, void *stream);
+int qrlsh_score_pairs(const int32_t *sig, const int64_t *norm2, int32_t P, const uint64_t *pairs,
+                      int64_t n, int32_t *milli_out, double *cos_out, uint64_t *edge_out,
+                      int32_t id_bits, void *stream);
+
+/* ---- a5: per-query top-K -----------------------------------------------------------
+ * Replaces argsort(values)[::-1][:K] per query, recommender.py:206-210, on the edge keys
+ * sorted ascending (so: src, value descending, dst ascending -- the documented
+ * tie-break; the reference's own tie order is arbitrary).  count-then-fill; the output
+ * is COO (src, dst, milli), at most K rows per src.
+ */
+int qrlsh_topk_count(const uint64_t *sorted_edges, int64_t n_edges, int32_t K, int32_t id_bits,
+                     void *workspace, size_t workspace_bytes, uint64_t *total_out, void *stream);
+int qrlsh_topk_fill(const uint64_t *sorted_edges, int64_t n_edges, int32_t K, int32_t id_bits,
+                    const void *workspace, int32_t *src_out, int32_t *dst_out, int32_t *milli_out,
+                    void *stream);
+
+/* ---- synthetic answer sets (bench / test input) ---------------
+ * Bit-identical twin of oracle/qr_oracle.c:qro_synth_*: a pure function of (seed, q).
+ * sizes: sizes_out[i] = |A(q0 + i)|; fill: rows at offsets[i] (offsets = exclusive scan).
+ */
+int qrlsh_synth_sizes(uint64_t seed, int64_t q0, int64_t nq_local, int64_t nq_total, int32_t cluster,
+                      uint32_t D, const uint32_t *cdf, int32_t ncdf, uint32_t rep_thresh24,
+                      int32_t *sizes_out, void *stream);
+int qrlsh_synth_fill(uint64_t seed, int64_t q0, int64_t nq_local, int64_t nq_total, int32_t cluster,
+                     uint32_t D, const uint32_t *cdf, int32_t ncdf, uint32_t rep_thresh24,
+                     const int64_t *offsets, int32_t *rows_out, void *stream);
+
+/* ---- optional per-kernel profiler ------------------------------------------------------
+ * When enabled, every kernel launch of the library is bracketed by two HIP events recorded on
+ * the launch stream.  qrlsh_prof_report waits for them and writes one "label count total_ms"
+ * line per kernel label into buf_host; returns the number of labels.  enable(on) also clears
+ * what was recorded so far.  bench.py uses this for the live roofline figures.
+ */
+int qrlsh_prof_enable(int on);
+int qrlsh_prof_report(char *buf_host, size_t buflen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QRLSH_H */

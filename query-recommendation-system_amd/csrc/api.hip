@@ -1,0 +1,108 @@
+// api.hip -- library-wide plumbing of libqrlsh: version, thread-local error text, and an
+// optional per-kernel profiler built on HIP events recorded on the launch stream.
+#include <stdarg.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void qrlsh_set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+QRLSH_EXPORT int qrlsh_version(void) { return 1; }
+QRLSH_EXPORT const char *qrlsh_last_error(void) { return g_err; }
+QRLSH_EXPORT uint64_t qrlsh_mix64_host(uint64_t x) { return qr_mix64(x); }
+
+// ---- profiler ---------------------------------------------------------------------------
+// When enabled, every kernel launch of the library is bracketed by two events on its own
+// stream; qrlsh_prof_report() synchronises them and sums hipEventElapsedTime per label.
+namespace {
+struct Rec { const char *label; hipEvent_t a, b; };
+std::mutex g_mu;
+bool g_on = false;
+std::vector<Rec> g_recs;
+std::vector<hipEvent_t> g_pool;
+
+hipEvent_t get_event() {
+  if (!g_pool.empty()) {
+    hipEvent_t e = g_pool.back();
+    g_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+}  // namespace
+
+int qr_prof_begin(const char *label, hipStream_t st) {
+  if (!g_on) return -1;
+  std::lock_guard<std::mutex> lk(g_mu);
+  Rec r{label, get_event(), get_event()};
+  if (!r.a || !r.b) return -1;
+  (void)hipEventRecord(r.a, st);
+  g_recs.push_back(r);
+  return (int)g_recs.size() - 1;
+}
+
+void qr_prof_end(int slot, hipStream_t st) {
+  if (slot < 0) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (slot < (int)g_recs.size()) (void)hipEventRecord(g_recs[slot].b, st);
+}
+
+QRLSH_EXPORT int qrlsh_prof_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (auto &r : g_recs) {
+    g_pool.push_back(r.a);
+    g_pool.push_back(r.b);
+  }
+  g_recs.clear();
+  g_on = on != 0;
+  return QRLSH_OK;
+}
+
+// Writes "label count total_ms\n" lines (one per label) into buf; returns the number of
+// labels, or a negative error.  Blocks until the recorded events have completed.
+QRLSH_EXPORT int qrlsh_prof_report(char *buf, size_t buflen) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  struct Acc { const char *label; long count; double ms; };
+  std::vector<Acc> acc;
+  for (auto &r : g_recs) {
+    if (hipEventSynchronize(r.b) != hipSuccess) {
+      qrlsh_set_error("qrlsh_prof_report: hipEventSynchronize failed");
+      return QRLSH_EHIP;
+    }
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, r.a, r.b);
+    bool found = false;
+    for (auto &a : acc)
+      if (strcmp(a.label, r.label) == 0) {
+        a.count++;
+        a.ms += ms;
+        found = true;
+        break;
+      }
+    if (!found) acc.push_back(Acc{r.label, 1, ms});
+  }
+  std::string out;
+  char line[160];
+  for (auto &a : acc) {
+    snprintf(line, sizeof(line), "%s %ld %.6f\n", a.label, a.count, a.ms);
+    out += line;
+  }
+  if (buf && buflen) {
+    strncpy(buf, out.c_str(), buflen - 1);
+    buf[buflen - 1] = 0;
+  }
+  return (int)acc.size();
+}

@@ -1,0 +1,89 @@
+// common.h -- shared device helpers and host-side error plumbing for libqrlsh (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/qrlsh.h"
+
+#define QRLSH_EXPORT extern "C" __attribute__((visibility("default")))
+
+constexpr int WAVE = 64;  // CDNA4 wavefront
+
+void qrlsh_set_error(const char *fmt, ...);
+
+#define QR_CHECK_ARG(cond, ...)        \
+  do {                                 \
+    if (!(cond)) {                     \
+      qrlsh_set_error(__VA_ARGS__);    \
+      return QRLSH_EINVAL;             \
+    }                                  \
+  } while (0)
+
+#define QR_LAUNCH_CHECK(name)                                                        \
+  do {                                                                               \
+    hipError_t e__ = hipGetLastError();                                              \
+    if (e__ != hipSuccess) {                                                         \
+      qrlsh_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));        \
+      return QRLSH_EHIP;                                                             \
+    }                                                                                \
+  } while (0)
+
+// optional per-kernel timing with HIP events on the launch stream (qrlsh_prof_* in api.hip)
+int qr_prof_begin(const char *label, hipStream_t st);
+void qr_prof_end(int slot, hipStream_t st);
+
+#define QR_LAUNCH(label, kern, grid, block, smem, st, ...)               \
+  do {                                                                   \
+    const int ps__ = qr_prof_begin(label, st);                           \
+    hipLaunchKernelGGL(kern, grid, block, smem, st, __VA_ARGS__);        \
+    qr_prof_end(ps__, st);                                               \
+  } while (0)
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// 64-bit bijective mixer (splitmix64 finaliser).  Bijective => equal mixes <=> equal keys
+// on all 64 bits; the grouping sort uses only the top 32 bits and resolves the (rare)
+// 32-bit collisions with a full-key compare at pair emission.
+__host__ __device__ static inline uint64_t qr_mix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+// key of a band whose r int16 values are all -1 (skipped by get_candidates, lsh.py:47)
+__host__ __device__ static inline uint64_t qr_empty_key(int r) {
+  return r >= 4 ? ~0ull : ((1ull << (16 * r)) - 1ull);
+}
+
+__device__ static inline int lane_id() { return threadIdx.x & (WAVE - 1); }
+
+// wave-level inclusive scan of a u64 via shuffles
+__device__ static inline uint64_t wave_incl_scan_u64(uint64_t v) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int d = 1; d < WAVE; d <<= 1) {
+    uint64_t o = __shfl_up(v, d, WAVE);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+
+// block-level exclusive scan of one u64 per thread (blockDim.x = 256); returns the
+// exclusive prefix for this thread and the block total in *total.  smem: >= 4 u64.
+__device__ static inline uint64_t block_excl_scan_u64_256(uint64_t v, uint64_t *smem, uint64_t *total) {
+  const int lane = lane_id(), w = threadIdx.x >> 6;
+  uint64_t inc = wave_incl_scan_u64(v);
+  if (lane == WAVE - 1) smem[w] = inc;
+  __syncthreads();
+  uint64_t base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    uint64_t s = smem[i];
+    if (i < w) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}

@@ -1,0 +1,261 @@
+// minhash.hip -- a1 (MinHash signatures) with fused a2 (band keys) and row norms.
+//
+// Reference: Recommender.compute_signatures, recommender.py:105-143, and the key
+// construction of LSH.make_subvecs / compute_buckets, lsh.py:17-38.
+//
+// Design (MI355X): the P permutations are stored TRANSPOSED, perm_t[d][0..P), so that
+//     sig[q][:] = elementwise-min over d in A(q) of perm_t[d][:]
+// is a row gather + min: every answer-set row is one contiguous 2P- or 4P-byte read
+// (16 B per lane, LPR lanes per row, 64/LPR rows in flight per wave-instruction) from a
+// table that lives in L2 / Infinity Cache (8 MB for D=32768, P=128, uint16).  One wave
+// owns one query at a time; a 256-thread workgroup owns QPB consecutive queries so the
+// band keys can be transposed through LDS and written band-major ([b][nq]) in full
+// 512-byte runs.
+#include "common.h"
+
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct TabVec;
+template <> struct TabVec<uint16_t> {
+  using type = u16x8;
+  static constexpr int N = 8;
+  __device__ static type init() { return (type)(0xFFFF); }
+};
+template <> struct TabVec<int32_t> {
+  using type = i32x4;
+  static constexpr int N = 4;
+  __device__ static type init() { return (type)(0x7FFFFFFF); }
+};
+
+template <typename V> __device__ static inline V vec_shfl_xor(V v, int m) {
+  typedef int i4 __attribute__((ext_vector_type(4)));
+  i4 x = __builtin_bit_cast(i4, v);
+  x.x = __shfl_xor(x.x, m, WAVE);
+  x.y = __shfl_xor(x.y, m, WAVE);
+  x.z = __shfl_xor(x.z, m, WAVE);
+  x.w = __shfl_xor(x.w, m, WAVE);
+  return __builtin_bit_cast(V, x);
+}
+
+// LPR = lanes per table row (power of two); one lane covers VEC = 16 B / sizeof(TabT)
+// permutations; G = 64 / LPR rows are fetched per wave-instruction.
+template <typename TabT, int LPR>
+__global__ __launch_bounds__(256) void minhash_kernel(const int64_t *__restrict__ offsets,
+                                                      const int32_t *__restrict__ rows, int64_t nq,
+                                                      const TabT *__restrict__ tab, int P, int P_stride,
+                                                      int32_t *__restrict__ sig, int64_t *__restrict__ norm2,
+                                                      uint64_t *__restrict__ keys, int b, int r, int qpb) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint16_t *s16 = reinterpret_cast<uint16_t *>(smem_raw);  // [qpb][ldk] low-16 signature image
+  using VecT = typename TabVec<TabT>::type;
+  constexpr int VEC = TabVec<TabT>::N;
+  constexpr int G = WAVE / LPR;
+  const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
+  const int g = lane / LPR, lig = lane % LPR;
+  const int64_t q0 = (int64_t)blockIdx.x * qpb;
+  const int ldk = P + 2;
+  const bool vec_store = (P % 4) == 0;
+
+  for (int ql = wave; ql < qpb; ql += 4) {
+    const int64_t q = q0 + ql;
+    if (q >= nq) break;  // wave-uniform
+    const int64_t lo = offsets[q];
+    const int n = (int)(offsets[q + 1] - lo);
+    int64_t nrm = 0;
+    for (int col0 = 0; col0 < P_stride; col0 += LPR * VEC) {
+      const int col = col0 + lig * VEC;
+      const bool colok = col < P_stride;
+      VecT acc = TabVec<TabT>::init();
+      for (int base = 0; base < n; base += WAVE) {
+        const int cnt = min(WAVE, n - base);
+        const int my = (lane < cnt) ? rows[lo + base + lane] : 0;
+        const int iters = (cnt + G - 1) / G;
+        for (int it = 0; it < iters; ++it) {
+          const int i = it * G + g;
+          const int d = __shfl(my, i & (WAVE - 1), WAVE);
+          if (i < cnt && colok) {
+            const VecT v = *reinterpret_cast<const VecT *>(tab + (size_t)d * P_stride + col);
+            acc = __builtin_elementwise_min(acc, v);
+          }
+        }
+      }
+#pragma unroll
+      for (int m = LPR; m < WAVE; m <<= 1) acc = __builtin_elementwise_min(acc, vec_shfl_xor(acc, m));
+
+      if (g == 0 && colok) {
+        int32_t out[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) out[e] = (n > 0) ? (int32_t)acc[e] : -1;
+        int32_t *dst = sig + (size_t)q * P + col;
+        if (vec_store && col + VEC <= P) {
+#pragma unroll
+          for (int e = 0; e < VEC; e += 4)
+            *reinterpret_cast<i32x4 *>(dst + e) = (i32x4){out[e], out[e + 1], out[e + 2], out[e + 3]};
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) nrm += (int64_t)out[e] * out[e];
+          if (keys) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) s16[ql * ldk + col + e] = (uint16_t)out[e];
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e)
+            if (col + e < P) {
+              dst[e] = out[e];
+              nrm += (int64_t)out[e] * out[e];
+              if (keys) s16[ql * ldk + col + e] = (uint16_t)out[e];
+            }
+        }
+      }
+    }
+    if (norm2) {
+#pragma unroll
+      for (int m = 1; m < WAVE; m <<= 1) nrm += __shfl_xor(nrm, m, WAVE);
+      if (lane == 0) norm2[q] = nrm;
+    }
+  }
+
+  if (keys) {
+    __syncthreads();
+    const int nql = (int)min((int64_t)qpb, nq - q0);
+    for (int idx = threadIdx.x; idx < qpb * b; idx += blockDim.x) {
+      const int ql = idx % qpb, band = idx / qpb;
+      if (ql < nql) {
+        const uint16_t *s = s16 + ql * ldk + band * r;
+        uint64_t k = 0;
+        for (int j = 0; j < r; ++j) k |= (uint64_t)s[j] << (16 * j);
+        keys[(size_t)band * nq + q0 + ql] = k;
+      }
+    }
+  }
+}
+
+// a2 standalone: band keys (band-major) from an int32 signature matrix.
+__global__ __launch_bounds__(256) void band_keys_kernel(const int32_t *__restrict__ sig, int64_t nq, int P,
+                                                        int b, int r, uint64_t *__restrict__ keys, int qpb) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint16_t *s16 = reinterpret_cast<uint16_t *>(smem_raw);
+  const int ldk = P + 2;
+  const int64_t q0 = (int64_t)blockIdx.x * qpb;
+  const int nql = (int)min((int64_t)qpb, nq - q0);
+  const int32_t *src = sig + (size_t)q0 * P;
+  for (int idx = threadIdx.x; idx < nql * P; idx += blockDim.x) {
+    const int ql = idx / P, c = idx - ql * P;
+    s16[ql * ldk + c] = (uint16_t)src[idx];
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < qpb * b; idx += blockDim.x) {
+    const int ql = idx % qpb, band = idx / qpb;
+    if (ql < nql) {
+      const uint16_t *s = s16 + ql * ldk + band * r;
+      uint64_t k = 0;
+      for (int j = 0; j < r; ++j) k |= (uint64_t)s[j] << (16 * j);
+      keys[(size_t)band * nq + q0 + ql] = k;
+    }
+  }
+}
+
+// exact squared L2 norm of every signature row; one wave per row.
+__global__ __launch_bounds__(256) void row_norms_kernel(const int32_t *__restrict__ sig, int64_t nq, int P,
+                                                        int64_t *__restrict__ norm2) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t q = wid; q < nq; q += nw) {
+    const int32_t *s = sig + (size_t)q * P;
+    int64_t acc = 0;
+    for (int c = lane; c < P; c += WAVE) acc += (int64_t)s[c] * s[c];
+#pragma unroll
+    for (int m = 1; m < WAVE; m <<= 1) acc += __shfl_xor(acc, m, WAVE);
+    if (lane == 0) norm2[q] = acc;
+  }
+}
+
+static int pick_qpb(int P) {
+  // LDS image = qpb * (P + 2) * 2 bytes; keep it <= 32 KiB so several workgroups share a CU
+  int qpb = 64;
+  while (qpb > 4 && (size_t)qpb * (P + 2) * 2 > 32768) qpb >>= 1;
+  return qpb;
+}
+
+template <typename TabT>
+static int launch_minhash(const int64_t *offsets, const int32_t *rows, int64_t nq, const void *perm_t, int P,
+                          int P_stride, int32_t *sig, int64_t *norm2, uint64_t *keys, int b, int r,
+                          hipStream_t st) {
+  constexpr int VEC = 16 / sizeof(TabT);
+  const int lanes = (P_stride + VEC - 1) / VEC;
+  const int qpb = pick_qpb(P);
+  const size_t smem = keys ? (size_t)qpb * (P + 2) * 2 : 0;
+  const dim3 grid((unsigned)ceil_div64(nq, qpb)), block(256);
+  const TabT *tab = static_cast<const TabT *>(perm_t);
+#define QR_MH(LPR_)                                                                                       \
+  QR_LAUNCH("minhash", (minhash_kernel<TabT, LPR_>), grid, block, smem, st, offsets, rows, nq, tab, P, P_stride, \
+                     sig, norm2, keys, b, r, qpb)
+  if (lanes <= 4) QR_MH(4);
+  else if (lanes <= 8) QR_MH(8);
+  else if (lanes <= 16) QR_MH(16);
+  else if (lanes <= 32) QR_MH(32);
+  else QR_MH(64);
+#undef QR_MH
+  QR_LAUNCH_CHECK("qrlsh_minhash");
+  return QRLSH_OK;
+}
+
+QRLSH_EXPORT int qrlsh_minhash(const int64_t *offsets, const int32_t *rows, int64_t nq, const void *perm_t,
+                               int32_t perm_dtype, int32_t P, int32_t P_stride, int32_t D, int32_t *sig_out,
+                               int64_t *norm2_out, uint64_t *keys_out, int32_t b, void *stream) {
+  QR_CHECK_ARG(nq >= 0 && P > 0 && D > 0 && P_stride >= P, "qrlsh_minhash: bad sizes nq=%lld P=%d P_stride=%d D=%d",
+               (long long)nq, P, P_stride, D);
+  QR_CHECK_ARG(offsets && perm_t && sig_out, "qrlsh_minhash: null pointer");
+  QR_CHECK_ARG(perm_dtype == QRLSH_PERM_U16 || perm_dtype == QRLSH_PERM_I32, "qrlsh_minhash: bad perm_dtype %d",
+               perm_dtype);
+  const int esz = perm_dtype == QRLSH_PERM_U16 ? 2 : 4;
+  QR_CHECK_ARG(((size_t)P_stride * esz) % 16 == 0, "qrlsh_minhash: P_stride*elem (%d*%d) must be a multiple of 16 B",
+               P_stride, esz);
+  QR_CHECK_ARG(perm_dtype != QRLSH_PERM_U16 || D <= 65536, "qrlsh_minhash: uint16 table needs D <= 65536 (D=%d)", D);
+  QR_CHECK_ARG(((uintptr_t)perm_t & 15) == 0 && ((uintptr_t)sig_out & 15) == 0, "qrlsh_minhash: 16-B alignment");
+  int r = 0;
+  if (keys_out) {
+    QR_CHECK_ARG(b > 0 && P % b == 0, "qrlsh_minhash: signature length %d not divisible by b=%d", P, b);
+    r = P / b;
+    if (r > 4) {
+      qrlsh_set_error("qrlsh_minhash: band width r=%d > 4 does not fit the 64-bit key", r);
+      return QRLSH_EUNSUPPORTED;
+    }
+  }
+  if (nq == 0) return QRLSH_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (perm_dtype == QRLSH_PERM_U16)
+    return launch_minhash<uint16_t>(offsets, rows, nq, perm_t, P, P_stride, sig_out, norm2_out, keys_out, b, r, st);
+  return launch_minhash<int32_t>(offsets, rows, nq, perm_t, P, P_stride, sig_out, norm2_out, keys_out, b, r, st);
+}
+
+QRLSH_EXPORT int qrlsh_band_keys(const int32_t *sig, int64_t nq, int32_t P, int32_t b, uint64_t *keys_out,
+                                 int64_t *norm2_out, void *stream) {
+  QR_CHECK_ARG(sig && keys_out && nq >= 0 && P > 0, "qrlsh_band_keys: bad arguments");
+  QR_CHECK_ARG(b > 0 && P % b == 0, "qrlsh_band_keys: signature length %d not divisible by b=%d", P, b);
+  const int r = P / b;
+  if (r > 4) {
+    qrlsh_set_error("qrlsh_band_keys: band width r=%d > 4 does not fit the 64-bit key", r);
+    return QRLSH_EUNSUPPORTED;
+  }
+  if (nq == 0) return QRLSH_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int qpb = pick_qpb(P);
+  QR_LAUNCH("band_keys", band_keys_kernel, dim3((unsigned)ceil_div64(nq, qpb)), dim3(256), (size_t)qpb * (P + 2) * 2, st,
+                     sig, nq, P, b, r, keys_out, qpb);
+  QR_LAUNCH_CHECK("qrlsh_band_keys");
+  if (norm2_out) return qrlsh_row_norms(sig, nq, P, norm2_out, stream);
+  return QRLSH_OK;
+}
+
+QRLSH_EXPORT int qrlsh_row_norms(const int32_t *sig, int64_t nq, int32_t P, int64_t *norm2_out, void *stream) {
+  QR_CHECK_ARG(sig && norm2_out && nq >= 0 && P > 0, "qrlsh_row_norms: bad arguments");
+  if (nq == 0) return QRLSH_OK;
+  const int64_t blocks = ceil_div64(nq, 4);
+  QR_LAUNCH("row_norms", row_norms_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), sig, nq, P, norm2_out);
+  QR_LAUNCH_CHECK("qrlsh_row_norms");
+  return QRLSH_OK;
+}

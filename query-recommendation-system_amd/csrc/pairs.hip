@@ -1,0 +1,291 @@
+// pairs.hip -- a3 candidate-pair enumeration and the two stream compactions (unique, top-K).
+//
+// Reference: LSH.get_candidates, lsh.py:40-55 (per bucket: combinations(hits, 2), skipping
+// single-member buckets and the all -1 key; a Python set removes cross-band duplicates),
+// and the per-query cut argsort(values)[::-1][:K], recommender.py:206-210.
+//
+// Input of the enumeration is, per band, the keys sorted by the top 32 bits of mix64(key)
+// together with their query ids (stable sort => ids ascending inside a run).  Record t
+// pairs with every earlier record u of its mix-run whose FULL key equals its own, so the
+// (rare) 32-bit mix collisions cost a compare and never a false pair.  Everything is
+// count-then-fill with per-workgroup offsets; nothing is allocated here.
+#include "common.h"
+
+constexpr int PAIR_THREADS = 256;
+constexpr int PAIR_IPT = 4;
+constexpr int PAIR_TILE = PAIR_THREADS * PAIR_IPT;  // records per workgroup (blocked: thread t owns 4 consecutive)
+
+constexpr int CMP_THREADS = 256;
+constexpr int CMP_IPT = 8;
+constexpr int CMP_TILE = CMP_THREADS * CMP_IPT;
+
+__device__ static inline uint32_t mix_hi(uint64_t k) { return (uint32_t)(qr_mix64(k) >> 32); }
+
+// number of earlier records in the same run with an identical key
+__device__ static inline uint32_t count_back(const uint64_t *__restrict__ k, int64_t t, uint64_t ek) {
+  const uint64_t kt = k[t];
+  if (kt == ek) return 0;
+  const uint32_t ht = mix_hi(kt);
+  uint32_t c = 0;
+  for (int64_t u = t - 1; u >= 0; --u) {
+    const uint64_t ku = k[u];
+    if (ku == kt) ++c;
+    else if (mix_hi(ku) != ht) break;
+  }
+  return c;
+}
+
+__global__ __launch_bounds__(PAIR_THREADS) void pairs_count_kernel(const uint64_t *__restrict__ keys, int64_t nq,
+                                                                   int ntiles, uint64_t ek,
+                                                                   uint64_t *__restrict__ blk) {
+  __shared__ uint64_t sm[4];
+  const int tile = blockIdx.x, band = blockIdx.y;
+  const uint64_t *k = keys + (size_t)band * nq;
+  const int64_t t0 = (int64_t)tile * PAIR_TILE + (int64_t)threadIdx.x * PAIR_IPT;
+  uint64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < PAIR_IPT; ++i)
+    if (t0 + i < nq) c += count_back(k, t0 + i, ek);
+  uint64_t total;
+  (void)block_excl_scan_u64_256(c, sm, &total);
+  if (threadIdx.x == 0) blk[(size_t)band * ntiles + tile] = total;
+}
+
+__global__ __launch_bounds__(PAIR_THREADS) void pairs_fill_kernel(const uint64_t *__restrict__ keys,
+                                                                  const uint32_t *__restrict__ ids, int64_t nq,
+                                                                  int ntiles, uint64_t ek,
+                                                                  const uint64_t *__restrict__ blk,
+                                                                  uint64_t *__restrict__ out) {
+  __shared__ uint64_t sm[4];
+  const int tile = blockIdx.x, band = blockIdx.y;
+  const uint64_t *k = keys + (size_t)band * nq;
+  const uint32_t *id = ids + (size_t)band * nq;
+  const int64_t t0 = (int64_t)tile * PAIR_TILE + (int64_t)threadIdx.x * PAIR_IPT;
+  uint32_t c[PAIR_IPT];
+  uint64_t mine = 0;
+#pragma unroll
+  for (int i = 0; i < PAIR_IPT; ++i) {
+    c[i] = (t0 + i < nq) ? count_back(k, t0 + i, ek) : 0;
+    mine += c[i];
+  }
+  uint64_t total;
+  uint64_t pos = blk[(size_t)band * ntiles + tile] + block_excl_scan_u64_256(mine, sm, &total);
+#pragma unroll
+  for (int i = 0; i < PAIR_IPT; ++i) {
+    if (c[i] == 0) continue;
+    const int64_t t = t0 + i;
+    const uint64_t kt = k[t];
+    const uint32_t it = id[t];
+    uint32_t left = c[i];
+    for (int64_t u = t - 1; left > 0; --u) {
+      if (k[u] == kt) {
+        const uint32_t iu = id[u];
+        const uint32_t a = iu < it ? iu : it, bb = iu < it ? it : iu;
+        out[pos++] = ((uint64_t)a << 32) | bb;
+        --left;
+      }
+    }
+  }
+}
+
+// in-place exclusive scan of m uint64 (one workgroup); the grand total goes to *total_out
+__global__ __launch_bounds__(1024) void scan_u64_kernel(uint64_t *__restrict__ a, int64_t m,
+                                                        uint64_t *__restrict__ total_out) {
+  __shared__ uint64_t wsum[16];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int64_t per = (m + 1023) / 1024;
+  const int64_t lo = min((int64_t)t * per, m), hi = min(lo + per, m);
+  uint64_t s = 0;
+  for (int64_t i = lo; i < hi; ++i) s += a[i];
+  const uint64_t inc = wave_incl_scan_u64(s);
+  if (lane == WAVE - 1) wsum[w] = inc;
+  __syncthreads();
+  uint64_t base = 0, tot = 0;
+  for (int i = 0; i < 16; ++i) {
+    if (i < w) base += wsum[i];
+    tot += wsum[i];
+  }
+  uint64_t run = base + inc - s;
+  for (int64_t i = lo; i < hi; ++i) {
+    const uint64_t v = a[i];
+    a[i] = run;
+    run += v;
+  }
+  if (t == 0) *total_out = tot;
+}
+
+// ---- stream compaction over a sorted uint64 array -------------------------------------
+// UNIQUE: keep the first of every run of equal words.
+// TOPK  : keep a directed edge iff fewer than K earlier edges share its src (edges are sorted
+//         by src, then value desc, then dst), i.e. iff t < K or src(a[t-K]) != src(a[t]).
+enum { PRED_UNIQUE = 0, PRED_TOPK = 1 };
+
+template <int PRED> __device__ static inline bool keep_at(const uint64_t *__restrict__ a, int64_t t, int K, int sh) {
+  if (PRED == PRED_UNIQUE) return t == 0 || a[t] != a[t - 1];
+  return t < K || (a[t - K] >> sh) != (a[t] >> sh);
+}
+
+template <int PRED>
+__global__ __launch_bounds__(CMP_THREADS) void compact_count_kernel(const uint64_t *__restrict__ a, int64_t n, int K,
+                                                                    int sh, uint64_t *__restrict__ blk) {
+  __shared__ uint64_t sm[4];
+  const int64_t t0 = (int64_t)blockIdx.x * CMP_TILE + (int64_t)threadIdx.x * CMP_IPT;
+  uint64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < CMP_IPT; ++i)
+    if (t0 + i < n) c += keep_at<PRED>(a, t0 + i, K, sh) ? 1 : 0;
+  uint64_t total;
+  (void)block_excl_scan_u64_256(c, sm, &total);
+  if (threadIdx.x == 0) blk[blockIdx.x] = total;
+}
+
+template <int PRED>
+__global__ __launch_bounds__(CMP_THREADS) void compact_fill_kernel(const uint64_t *__restrict__ a, int64_t n, int K,
+                                                                   int sh, int id_bits,
+                                                                   const uint64_t *__restrict__ blk,
+                                                                   uint64_t *__restrict__ out_u64,
+                                                                   int32_t *__restrict__ src_out,
+                                                                   int32_t *__restrict__ dst_out,
+                                                                   int32_t *__restrict__ milli_out) {
+  __shared__ uint64_t sm[4];
+  const int64_t t0 = (int64_t)blockIdx.x * CMP_TILE + (int64_t)threadIdx.x * CMP_IPT;
+  bool keep[CMP_IPT];
+  uint64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < CMP_IPT; ++i) {
+    keep[i] = (t0 + i < n) && keep_at<PRED>(a, t0 + i, K, sh);
+    c += keep[i] ? 1 : 0;
+  }
+  uint64_t total;
+  uint64_t pos = blk[blockIdx.x] + block_excl_scan_u64_256(c, sm, &total);
+#pragma unroll
+  for (int i = 0; i < CMP_IPT; ++i) {
+    if (!keep[i]) continue;
+    const uint64_t v = a[t0 + i];
+    if (PRED == PRED_UNIQUE) {
+      out_u64[pos] = v;
+    } else {
+      const uint64_t idm = (1ull << id_bits) - 1ull;
+      src_out[pos] = (int32_t)(v >> sh);
+      dst_out[pos] = (int32_t)(v & idm);
+      milli_out[pos] = 1000 - (int32_t)((v >> id_bits) & 0x7FFull);
+    }
+    ++pos;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+QRLSH_EXPORT size_t qrlsh_pairs_workspace_bytes(int64_t nq, int32_t b) {
+  if (nq <= 0 || b <= 0) return 16;
+  return (size_t)b * ceil_div64(nq, PAIR_TILE) * sizeof(uint64_t);
+}
+
+QRLSH_EXPORT int qrlsh_pairs_count(const uint64_t *sorted_keys, int64_t nq, int32_t b, int32_t r, void *workspace,
+                                   size_t workspace_bytes, uint64_t *total_out, void *stream) {
+  QR_CHECK_ARG(nq >= 0 && b > 0 && r > 0 && r <= 4, "qrlsh_pairs_count: bad sizes nq=%lld b=%d r=%d", (long long)nq,
+               b, r);
+  QR_CHECK_ARG(total_out && workspace, "qrlsh_pairs_count: null pointer");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (nq == 0) {
+    if (hipMemsetAsync(total_out, 0, sizeof(uint64_t), st) != hipSuccess) {
+      qrlsh_set_error("hipMemsetAsync failed");
+      return QRLSH_EHIP;
+    }
+    return QRLSH_OK;
+  }
+  QR_CHECK_ARG(sorted_keys, "qrlsh_pairs_count: null keys");
+  if (workspace_bytes < qrlsh_pairs_workspace_bytes(nq, b)) {
+    qrlsh_set_error("qrlsh_pairs_count: workspace %zu < %zu bytes", workspace_bytes,
+                    qrlsh_pairs_workspace_bytes(nq, b));
+    return QRLSH_EWORKSPACE;
+  }
+  const int ntiles = (int)ceil_div64(nq, PAIR_TILE);
+  uint64_t *blk = static_cast<uint64_t *>(workspace);
+  QR_LAUNCH("pairs_count", pairs_count_kernel, dim3(ntiles, b), dim3(PAIR_THREADS), 0, st, sorted_keys, nq, ntiles,
+                     qr_empty_key(r), blk);
+  QR_LAUNCH("scan_blocks", scan_u64_kernel, dim3(1), dim3(1024), 0, st, blk, (int64_t)ntiles * b, total_out);
+  QR_LAUNCH_CHECK("qrlsh_pairs_count");
+  return QRLSH_OK;
+}
+
+QRLSH_EXPORT int qrlsh_pairs_fill(const uint64_t *sorted_keys, const uint32_t *sorted_ids, int64_t nq, int32_t b,
+                                  int32_t r, const void *workspace, uint64_t *pairs_out, void *stream) {
+  QR_CHECK_ARG(nq >= 0 && b > 0 && r > 0 && r <= 4, "qrlsh_pairs_fill: bad sizes");
+  if (nq == 0) return QRLSH_OK;
+  QR_CHECK_ARG(sorted_keys && sorted_ids && workspace && pairs_out, "qrlsh_pairs_fill: null pointer");
+  const int ntiles = (int)ceil_div64(nq, PAIR_TILE);
+  QR_LAUNCH("pairs_fill", pairs_fill_kernel, dim3(ntiles, b), dim3(PAIR_THREADS), 0, static_cast<hipStream_t>(stream),
+                     sorted_keys, sorted_ids, nq, ntiles, qr_empty_key(r), static_cast<const uint64_t *>(workspace),
+                     pairs_out);
+  QR_LAUNCH_CHECK("qrlsh_pairs_fill");
+  return QRLSH_OK;
+}
+
+QRLSH_EXPORT size_t qrlsh_compact_workspace_bytes(int64_t n) {
+  if (n <= 0) return 16;
+  return (size_t)ceil_div64(n, CMP_TILE) * sizeof(uint64_t);
+}
+
+template <int PRED>
+static int compact_count(const uint64_t *a, int64_t n, int K, int sh, void *workspace, size_t workspace_bytes,
+                         uint64_t *total_out, void *stream, const char *name) {
+  QR_CHECK_ARG(n >= 0 && total_out && workspace, "%s: bad arguments", name);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n == 0) {
+    if (hipMemsetAsync(total_out, 0, sizeof(uint64_t), st) != hipSuccess) {
+      qrlsh_set_error("hipMemsetAsync failed");
+      return QRLSH_EHIP;
+    }
+    return QRLSH_OK;
+  }
+  QR_CHECK_ARG(a, "%s: null input", name);
+  if (workspace_bytes < qrlsh_compact_workspace_bytes(n)) {
+    qrlsh_set_error("%s: workspace %zu < %zu bytes", name, workspace_bytes, qrlsh_compact_workspace_bytes(n));
+    return QRLSH_EWORKSPACE;
+  }
+  const int64_t nblk = ceil_div64(n, CMP_TILE);
+  uint64_t *blk = static_cast<uint64_t *>(workspace);
+  QR_LAUNCH(PRED == PRED_UNIQUE ? "unique_count" : "topk_count", (compact_count_kernel<PRED>), dim3((unsigned)nblk), dim3(CMP_THREADS), 0, st, a, n, K, sh, blk);
+  QR_LAUNCH("scan_blocks", scan_u64_kernel, dim3(1), dim3(1024), 0, st, blk, nblk, total_out);
+  QR_LAUNCH_CHECK(name);
+  return QRLSH_OK;
+}
+
+QRLSH_EXPORT int qrlsh_unique_count(const uint64_t *sorted, int64_t n, void *workspace, size_t workspace_bytes,
+                                    uint64_t *total_out, void *stream) {
+  return compact_count<PRED_UNIQUE>(sorted, n, 0, 0, workspace, workspace_bytes, total_out, stream,
+                                    "qrlsh_unique_count");
+}
+
+QRLSH_EXPORT int qrlsh_unique_fill(const uint64_t *sorted, int64_t n, const void *workspace, uint64_t *out,
+                                   void *stream) {
+  QR_CHECK_ARG(n >= 0, "qrlsh_unique_fill: bad n");
+  if (n == 0) return QRLSH_OK;
+  QR_CHECK_ARG(sorted && workspace && out, "qrlsh_unique_fill: null pointer");
+  QR_LAUNCH("unique_fill", (compact_fill_kernel<PRED_UNIQUE>), dim3((unsigned)ceil_div64(n, CMP_TILE)), dim3(CMP_THREADS), 0,
+                     static_cast<hipStream_t>(stream), sorted, n, 0, 0, 0, static_cast<const uint64_t *>(workspace),
+                     out, nullptr, nullptr, nullptr);
+  QR_LAUNCH_CHECK("qrlsh_unique_fill");
+  return QRLSH_OK;
+}
+
+QRLSH_EXPORT int qrlsh_topk_count(const uint64_t *sorted_edges, int64_t n_edges, int32_t K, int32_t id_bits,
+                                  void *workspace, size_t workspace_bytes, uint64_t *total_out, void *stream) {
+  QR_CHECK_ARG(K > 0 && id_bits > 0 && id_bits <= 26, "qrlsh_topk_count: bad K=%d or id_bits=%d (need <= 26)", K,
+               id_bits);
+  return compact_count<PRED_TOPK>(sorted_edges, n_edges, K, id_bits + 11, workspace, workspace_bytes, total_out, stream,
+                                  "qrlsh_topk_count");
+}
+
+QRLSH_EXPORT int qrlsh_topk_fill(const uint64_t *sorted_edges, int64_t n_edges, int32_t K, int32_t id_bits,
+                                 const void *workspace, int32_t *src_out, int32_t *dst_out, int32_t *milli_out,
+                                 void *stream) {
+  QR_CHECK_ARG(K > 0 && id_bits > 0 && id_bits <= 26 && n_edges >= 0, "qrlsh_topk_fill: bad arguments");
+  if (n_edges == 0) return QRLSH_OK;
+  QR_CHECK_ARG(sorted_edges && workspace && src_out && dst_out && milli_out, "qrlsh_topk_fill: null pointer");
+  QR_LAUNCH("topk_fill", (compact_fill_kernel<PRED_TOPK>), dim3((unsigned)ceil_div64(n_edges, CMP_TILE)),
+                     dim3(CMP_THREADS), 0, static_cast<hipStream_t>(stream), sorted_edges, n_edges, K, id_bits + 11,
+                     id_bits, static_cast<const uint64_t *>(workspace), nullptr, src_out, dst_out, milli_out);
+  QR_LAUNCH_CHECK("qrlsh_topk_fill");
+  return QRLSH_OK;
+}

@@ -1,0 +1,92 @@
+// score.hip -- a5: cosine of the MinHash-value vectors of every candidate pair.
+//
+// Reference: recommender.py:203-204,
+//     values = np.around(cosine_similarity([sig_i, sig_j1, ...])[0][1:], 3)
+// (sklearn builds the whole (k+1)^2 Gram matrix in float64 and keeps row 0).  Here each
+// unique pair is scored once: exact integer dot product of the two signature rows read
+// from HBM (16 B per lane, 16 lanes per pair, 4 pairs per wave-instruction), the squared
+// norms come precomputed from the MinHash kernel, and
+//     cos = dot / (sqrt(na) * sqrt(nb))   in float64,  milli = rint(cos * 1000)
+// so that milli / 1000.0 == np.around(cos, 3).  Integer dot/norms are exact (|sig| < 2^31,
+// P * D^2 < 2^63), so the only rounding is the final divide -- within 2 ulp of sklearn's
+// normalise-then-multiply and identical after the rounding to 3 decimals (checked on every
+// golden pair).  HBM-bound: 2 * 4P bytes of rows per pair.
+#include "common.h"
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SCORE_LPP = 16;  // lanes per pair
+
+template <bool VEC4>
+__global__ __launch_bounds__(256) void score_pairs_kernel(const int32_t *__restrict__ sig,
+                                                          const int64_t *__restrict__ norm2, int P,
+                                                          const uint64_t *__restrict__ pairs, int64_t n,
+                                                          int32_t *__restrict__ milli, double *__restrict__ cosv,
+                                                          uint64_t *__restrict__ edges, int id_bits) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int lig = lane & (SCORE_LPP - 1);
+  const int64_t group = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / SCORE_LPP);
+  const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) / SCORE_LPP;
+  // trip count is uniform across the wave: round n up to the groups of one wave
+  const int64_t gpw = WAVE / SCORE_LPP;
+  const int64_t iters = (n + ngroups - 1) / ngroups;
+  for (int64_t it = 0; it < iters; ++it) {
+    const int64_t t = it * ngroups + group;
+    const bool live = t < n;
+    uint64_t pr = 0;
+    if (live) pr = pairs[t];
+    const uint32_t i = (uint32_t)(pr >> 32), j = (uint32_t)pr;
+    const int32_t *a = sig + (size_t)i * P;
+    const int32_t *c = sig + (size_t)j * P;
+    int64_t dot = 0;
+    if (live) {
+      if (VEC4) {
+        for (int col = lig * 4; col < P; col += SCORE_LPP * 4) {
+          const i32x4 x = *reinterpret_cast<const i32x4 *>(a + col);
+          const i32x4 y = *reinterpret_cast<const i32x4 *>(c + col);
+          dot += (int64_t)x.x * y.x + (int64_t)x.y * y.y + (int64_t)x.z * y.z + (int64_t)x.w * y.w;
+        }
+      } else {
+        for (int col = lig; col < P; col += SCORE_LPP) dot += (int64_t)a[col] * c[col];
+      }
+    }
+#pragma unroll
+    for (int m = 1; m < SCORE_LPP; m <<= 1) dot += __shfl_xor(dot, m, WAVE);
+    if (live && lig == 0) {
+      const int64_t na = norm2[i], nb = norm2[j];
+      double cs = 0.0;
+      if (na != 0 && nb != 0) cs = (double)dot / (sqrt((double)na) * sqrt((double)nb));
+      const int32_t mi = (int32_t)rint(cs * 1000.0);
+      milli[t] = mi;
+      if (cosv) cosv[t] = cs;
+      if (edges) {
+        const uint64_t inv = (uint64_t)(1000 - mi);
+        edges[2 * t] = ((uint64_t)i << (id_bits + 11)) | (inv << id_bits) | j;
+        edges[2 * t + 1] = ((uint64_t)j << (id_bits + 11)) | (inv << id_bits) | i;
+      }
+    }
+    (void)gpw;
+  }
+}
+
+QRLSH_EXPORT int qrlsh_score_pairs(const int32_t *sig, const int64_t *norm2, int32_t P, const uint64_t *pairs,
+                                   int64_t n, int32_t *milli_out, double *cos_out, uint64_t *edge_out,
+                                   int32_t id_bits, void *stream) {
+  QR_CHECK_ARG(n >= 0 && P > 0, "qrlsh_score_pairs: bad sizes n=%lld P=%d", (long long)n, P);
+  if (n == 0) return QRLSH_OK;
+  QR_CHECK_ARG(sig && norm2 && pairs && milli_out, "qrlsh_score_pairs: null pointer");
+  if (edge_out) QR_CHECK_ARG(id_bits > 0 && id_bits <= 26, "qrlsh_score_pairs: id_bits=%d must be in [1,26]", id_bits);
+  const bool vec4 = (P % 4 == 0) && (((uintptr_t)sig & 15) == 0);
+  const int64_t groups_per_block = 256 / SCORE_LPP;
+  int64_t blocks = ceil_div64(n, groups_per_block);
+  if (blocks > 256 * 32) blocks = 256 * 32;  // grid-stride beyond 32 workgroups per CU
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (vec4)
+    QR_LAUNCH("score_pairs", (score_pairs_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, st, sig, norm2, P, pairs, n,
+                       milli_out, cos_out, edge_out, id_bits);
+  else
+    QR_LAUNCH("score_pairs", (score_pairs_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, st, sig, norm2, P, pairs, n,
+                       milli_out, cos_out, edge_out, id_bits);
+  QR_LAUNCH_CHECK("qrlsh_score_pairs");
+  return QRLSH_OK;
+}

@@ -1,0 +1,285 @@
+"""Thin torch-tensor wrappers over the C ABI (include/qrlsh.h).
+
+Tensors are device buffers only: every function checks device / dtype / contiguity, passes
+raw pointers and the current HIP stream to libqrlsh, and returns tensors.  64-bit unsigned
+words (band keys, pairs, edge keys) are carried in torch.int64 tensors (bit patterns).
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_vp = ctypes.c_void_p
+
+
+def _stream():
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    return _vp(t.data_ptr())
+
+
+def _need(t, dtype, name, ndim=None):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise TypeError("%s must be a CUDA/HIP tensor" % name)
+    if t.dtype != dtype:
+        raise TypeError("%s must have dtype %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    if ndim is not None and t.dim() != ndim:
+        raise ValueError("%s must have %d dimensions" % (name, ndim))
+    return t
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def id_bits_for(nq):
+    """bits needed for a query id in [0, nq)"""
+    return max(1, int(nq - 1).bit_length()) if nq > 1 else 1
+
+
+# ---------------------------------------------------------------------------
+# permutation table (host side; recommender.py:120)
+# ---------------------------------------------------------------------------
+def legacy_permutations(P, D, seed=None, rng=None):
+    """The P consecutive np.random.permutation(D) draws of recommender.py:120.
+
+    seed given -> RandomState(seed) (the same stream np.random.seed(seed) selects);
+    otherwise `rng` (default: the global legacy np.random, consumed exactly like the
+    reference consumes it).  Returns int32 [P][D].
+    """
+    if seed is not None:
+        rng = np.random.RandomState(seed)
+    elif rng is None:
+        rng = np.random
+    out = np.empty((P, D), dtype=np.int32)
+    for p in range(P):
+        out[p] = rng.permutation(D)
+    return out
+
+
+class PermTable:
+    """Transposed permutation table resident in HBM: tab[d][0..P) = perm_0[d] .. perm_{P-1}[d]."""
+
+    def __init__(self, tab, code, P, P_stride, D):
+        self.tab, self.code, self.P, self.P_stride, self.D = tab, code, P, P_stride, D
+
+
+def perm_table(perms, device="cuda", force_i32=False):
+    """Upload int [P][D] permutations as the transposed [D][P_stride] table the MinHash
+    kernel gathers from: uint16 when D <= 65536 (half the gather bytes), else int32."""
+    perms = np.asarray(perms)
+    P, D = perms.shape
+    if D <= 65536 and not force_i32:
+        stride = (P + 7) // 8 * 8
+        tab = np.full((D, stride), 0xFFFF, dtype=np.uint16)
+        tab[:, :P] = perms.T
+        t = torch.from_numpy(tab.view(np.int16)).to(device)
+        code = _lib.PERM_U16
+    else:
+        stride = (P + 3) // 4 * 4
+        tab = np.full((D, stride), 0x7FFFFFFF, dtype=np.int32)
+        tab[:, :P] = perms.T
+        t = torch.from_numpy(tab).to(device)
+        code = _lib.PERM_I32
+    return PermTable(t, code, P, stride, D)
+
+
+# ---------------------------------------------------------------------------
+# a1 / a2
+# ---------------------------------------------------------------------------
+def minhash(offsets, rows, table, b=None, want_norm=True):
+    """sig[q][p] = min over the answer set of perm_p (recommender.py:105-143), -1 if empty.
+    Returns (sig int32 [nq,P], norm2 int64 [nq] | None, keys int64 [b,nq] | None)."""
+    lib = _lib.load()
+    _need(offsets, torch.int64, "offsets", 1)
+    _need(rows, torch.int32, "rows", 1)
+    nq = offsets.numel() - 1
+    if nq < 0:
+        raise ValueError("offsets must have nq+1 entries")
+    P = table.P
+    dev = offsets.device
+    if b is not None and P % b != 0:
+        raise AssertionError("signature length %d not divisible by b=%d" % (P, b))  # lsh.py:20
+    sig = torch.empty((nq, P), dtype=torch.int32, device=dev)
+    norm2 = torch.empty((nq,), dtype=torch.int64, device=dev) if want_norm else None
+    keys = torch.empty((b, nq), dtype=torch.int64, device=dev) if b is not None else None
+    _lib.check(lib.qrlsh_minhash(_ptr(offsets), _ptr(rows), nq, _ptr(table.tab), table.code, P, table.P_stride,
+                                 table.D, _ptr(sig), _ptr(norm2), _ptr(keys), b if b is not None else 0, _stream()))
+    return sig, norm2, keys
+
+
+def band_keys(sig, b, want_norm=False):
+    """Band keys of an int32 signature matrix (lsh.py:17-38) -> int64 [b,nq] (+ norm2)."""
+    lib = _lib.load()
+    _need(sig, torch.int32, "sig", 2)
+    nq, P = sig.shape
+    if b <= 0 or P % b != 0:
+        raise AssertionError("signature length %d not divisible by b=%d" % (P, b))  # lsh.py:20
+    keys = torch.empty((b, nq), dtype=torch.int64, device=sig.device)
+    norm2 = torch.empty((nq,), dtype=torch.int64, device=sig.device) if want_norm else None
+    _lib.check(lib.qrlsh_band_keys(_ptr(sig), nq, P, b, _ptr(keys), _ptr(norm2), _stream()))
+    return (keys, norm2) if want_norm else keys
+
+
+def row_norms(sig):
+    lib = _lib.load()
+    _need(sig, torch.int32, "sig", 2)
+    nq, P = sig.shape
+    out = torch.empty((nq,), dtype=torch.int64, device=sig.device)
+    _lib.check(lib.qrlsh_row_norms(_ptr(sig), nq, P, _ptr(out), _stream()))
+    return out
+
+
+# ---------------------------------------------------------------------------
+# radix sort
+# ---------------------------------------------------------------------------
+def sort_u64(keys, vals=None, bit_lo=0, bit_hi=64, mix=False, iota=False):
+    """Stable LSD radix sort of each row of keys (int64 bit patterns, unsigned order) over
+    bits [bit_lo, bit_hi) (of mix64(key) when mix).  `keys` (and vals) are consumed as one
+    of the two ping-pong buffers.  Returns (sorted_keys, sorted_vals | None)."""
+    lib = _lib.load()
+    _need(keys, torch.int64, "keys")
+    k2 = keys if keys.dim() == 2 else keys.view(1, -1)
+    nbatch, n = k2.shape
+    if iota and vals is None:
+        vals = torch.empty((nbatch, n), dtype=torch.int32, device=keys.device)
+    if vals is not None:
+        _need(vals, torch.int32, "vals")
+        if vals.numel() != k2.numel():
+            raise ValueError("vals must match keys")
+    kb = torch.empty_like(k2)
+    vb = torch.empty_like(vals) if vals is not None else None
+    nbytes = lib.qrlsh_sort_workspace_bytes(n, nbatch)
+    ws = _ws(nbytes, keys.device)
+    flags = (_lib.SORT_MIX if mix else 0) | (_lib.SORT_IOTA if iota else 0)
+    rc = _lib.check(lib.qrlsh_sort_u64(_ptr(k2), _ptr(kb), _ptr(vals), _ptr(vb), n, nbatch, bit_lo, bit_hi, flags,
+                                       _ptr(ws), ws.numel(), _stream()))
+    ko = kb if rc == 1 else k2
+    vo = (vb if rc == 1 else vals) if vals is not None else None
+    if keys.dim() == 1:
+        ko = ko.view(-1)
+        vo = vo.view(-1) if vo is not None else None
+    elif vo is not None:
+        vo = vo.view(nbatch, n)
+    return ko, vo
+
+
+def bucket_sort(keys):
+    """Group equal band keys (replaces the dict buckets of lsh.py:31-38): per band, sort
+    (key, query id) by the top 32 bits of mix64(key).  keys int64 [b,nq] (consumed).
+    Returns (sorted_keys [b,nq], sorted_ids int32 [b,nq])."""
+    _need(keys, torch.int64, "keys", 2)
+    return sort_u64(keys, None, 32, 64, mix=True, iota=True)
+
+
+# ---------------------------------------------------------------------------
+# a3: pairs
+# ---------------------------------------------------------------------------
+def emit_pairs(sorted_keys, sorted_ids, r):
+    """All (i<j) pairs of every non-empty bucket with > 1 member, every band
+    (lsh.py:42-53), as int64 i<<32|j, duplicates across bands included."""
+    lib = _lib.load()
+    _need(sorted_keys, torch.int64, "sorted_keys", 2)
+    _need(sorted_ids, torch.int32, "sorted_ids", 2)
+    b, nq = sorted_keys.shape
+    dev = sorted_keys.device
+    ws = _ws(lib.qrlsh_pairs_workspace_bytes(nq, b), dev)
+    total = torch.zeros(1, dtype=torch.int64, device=dev)
+    _lib.check(lib.qrlsh_pairs_count(_ptr(sorted_keys), nq, b, r, _ptr(ws), ws.numel(), _ptr(total), _stream()))
+    n = int(total.item())
+    pairs = torch.empty((n,), dtype=torch.int64, device=dev)
+    if n:
+        _lib.check(lib.qrlsh_pairs_fill(_ptr(sorted_keys), _ptr(sorted_ids), nq, b, r, _ptr(ws), _ptr(pairs),
+                                        _stream()))
+    return pairs
+
+
+def unique_sorted(a):
+    lib = _lib.load()
+    _need(a, torch.int64, "a", 1)
+    n = a.numel()
+    ws = _ws(lib.qrlsh_compact_workspace_bytes(n), a.device)
+    total = torch.zeros(1, dtype=torch.int64, device=a.device)
+    _lib.check(lib.qrlsh_unique_count(_ptr(a), n, _ptr(ws), ws.numel(), _ptr(total), _stream()))
+    m = int(total.item())
+    out = torch.empty((m,), dtype=torch.int64, device=a.device)
+    if m:
+        _lib.check(lib.qrlsh_unique_fill(_ptr(a), n, _ptr(ws), _ptr(out), _stream()))
+    return out
+
+
+def sort_pairs(pairs, nq):
+    """sort i<<32|j words: LSD over j's bits, then i's bits"""
+    ib = id_bits_for(nq)
+    p, _ = sort_u64(pairs, None, 0, ib)
+    p, _ = sort_u64(p, None, 32, 32 + ib)
+    return p
+
+
+def candidate_pairs(keys, r, stats=None):
+    """get_candidates (lsh.py:40-55) on band-major keys [b,nq] (consumed): sorted unique
+    int64 array of i<<32|j, i<j."""
+    b, nq = keys.shape
+    sk, sid = bucket_sort(keys)
+    emitted = emit_pairs(sk, sid, r)
+    if stats is not None:
+        stats["emitted_pairs"] = int(emitted.numel())
+    if emitted.numel() == 0:
+        return emitted
+    return unique_sorted(sort_pairs(emitted, nq))
+
+
+# ---------------------------------------------------------------------------
+# a5: scoring and top-K
+# ---------------------------------------------------------------------------
+def score_pairs(sig, norm2, pairs, want_cos=False, edge_id_bits=None):
+    """milli = rint(1000 * cosine(sig_i, sig_j)) per pair (recommender.py:203-204).
+    Returns (milli int32, cos float64 | None, edges int64 [2n] | None)."""
+    lib = _lib.load()
+    _need(sig, torch.int32, "sig", 2)
+    _need(norm2, torch.int64, "norm2", 1)
+    _need(pairs, torch.int64, "pairs", 1)
+    n = pairs.numel()
+    dev = sig.device
+    milli = torch.empty((n,), dtype=torch.int32, device=dev)
+    cosv = torch.empty((n,), dtype=torch.float64, device=dev) if want_cos else None
+    edges = torch.empty((2 * n,), dtype=torch.int64, device=dev) if edge_id_bits is not None else None
+    _lib.check(lib.qrlsh_score_pairs(_ptr(sig), _ptr(norm2), sig.shape[1], _ptr(pairs), n, _ptr(milli), _ptr(cosv),
+                                     _ptr(edges), edge_id_bits if edge_id_bits is not None else 0, _stream()))
+    return milli, cosv, edges
+
+
+def topk_edges(edges, K, id_bits):
+    """Per-query top-K (recommender.py:206-210) from the directed edge keys written by
+    score_pairs: -> (src, dst, milli) int32, sorted by src, value desc, dst asc; <= K per src."""
+    lib = _lib.load()
+    _need(edges, torch.int64, "edges", 1)
+    dev = edges.device
+    n = edges.numel()
+    if n == 0:
+        z = torch.empty((0,), dtype=torch.int32, device=dev)
+        return z, z.clone(), z.clone()
+    se, _ = sort_u64(edges, None, 0, 2 * id_bits + 11)
+    ws = _ws(lib.qrlsh_compact_workspace_bytes(n), dev)
+    total = torch.zeros(1, dtype=torch.int64, device=dev)
+    _lib.check(lib.qrlsh_topk_count(_ptr(se), n, K, id_bits, _ptr(ws), ws.numel(), _ptr(total), _stream()))
+    m = int(total.item())
+    src = torch.empty((m,), dtype=torch.int32, device=dev)
+    dst = torch.empty((m,), dtype=torch.int32, device=dev)
+    val = torch.empty((m,), dtype=torch.int32, device=dev)
+    _lib.check(lib.qrlsh_topk_fill(_ptr(se), n, K, id_bits, _ptr(ws), _ptr(src), _ptr(dst), _ptr(val), _stream()))
+    return src, dst, val
+
+
+def max_candidates(nq):
+    """K = round(log_1.5 nq), recommender.py:151"""
+    return round(math.log(nq, 1.5))

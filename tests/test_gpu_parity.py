@@ -1,0 +1,320 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): the HIP path, called through the
+C ABI (ctypes, qrlsh.ops), against the oracle and the golden vectors captured from the
+reference.  Integer / index work is bit-exact; the cosine is compared after the reference's
+own rounding to 3 decimals (np.around, recommender.py:203)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import FULL, PIECES, GOLDEN, load, pairs_u64, check_topk_tie_aware
+
+pytestmark = pytest.mark.gpu
+
+import qrlsh  # noqa: E402
+from qrlsh import ops, pipeline  # noqa: E402
+from oracle import oracle as O  # noqa: E402  (checker only)
+
+DEV = "cuda"
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def u64(t):
+    return t.cpu().numpy().view(np.uint64)
+
+
+# ---------------------------------------------------------------------------- a1 / a2
+@pytest.mark.parametrize("force_i32", [False, True])
+@pytest.mark.parametrize("name", FULL + PIECES)
+def test_minhash_matches_reference_golden(name, force_i32):
+    g = load(name)
+    P, D, b = int(g["P"]), int(g["D"]), int(g["b"])
+    perms = ops.legacy_permutations(P, D, seed=int(g["seed"]))
+    table = ops.perm_table(perms, DEV, force_i32=force_i32)
+    sig, norm2, keys = ops.minhash(dev(g["offsets"]), dev(g["rows"]), table, b=b)
+    torch.cuda.synchronize()
+    assert np.array_equal(sig.cpu().numpy(), g["sig"])
+    assert np.array_equal(norm2.cpu().numpy(), (g["sig"].astype(np.int64) ** 2).sum(1))
+    assert np.array_equal(u64(keys).T, O.band_keys(g["sig"], b))
+    # standalone a2 agrees with the fused one
+    k2, n2 = ops.band_keys(sig, b, want_norm=True)
+    assert torch.equal(k2, keys) and torch.equal(n2, norm2)
+    assert torch.equal(ops.row_norms(sig), norm2)
+
+
+def test_minhash_odd_shapes():
+    rng = np.random.default_rng(3)
+    for (nq, D, P, b) in [(1, 7, 5, 5), (3, 70000, 12, 4), (130, 50, 15, 5), (257, 300, 520, 130), (65, 1000, 33, 11)]:
+        sets = [np.unique(rng.integers(0, D, size=rng.integers(0, 90))) for _ in range(nq)]
+        off = np.zeros(nq + 1, np.int64)
+        off[1:] = np.cumsum([len(s) for s in sets])
+        rows = (np.concatenate(sets) if nq else np.zeros(0)).astype(np.int32)
+        perm = O.legacy_permutations(1, P, D)
+        ref = O.minhash(off, rows, perm)
+        for force in (False, True):
+            table = ops.perm_table(perm, DEV, force_i32=force)
+            sig, norm2, keys = ops.minhash(dev(off), dev(rows), table, b=b)
+            assert np.array_equal(sig.cpu().numpy(), ref)
+            assert np.array_equal(u64(keys).T, O.band_keys(ref, b))
+
+
+def test_minhash_empty_input_and_errors():
+    perm = O.legacy_permutations(0, 8, 16)
+    table = ops.perm_table(perm, DEV)
+    sig, norm2, keys = ops.minhash(dev(np.zeros(1, np.int64)), dev(np.zeros(0, np.int32)), table, b=4)
+    assert sig.shape == (0, 8) and keys.shape == (4, 0)
+    with pytest.raises(AssertionError):
+        ops.minhash(dev(np.zeros(2, np.int64)), dev(np.zeros(0, np.int32)), table, b=3)
+    table16 = ops.perm_table(O.legacy_permutations(0, 16, 16), DEV)
+    with pytest.raises(NotImplementedError):  # r = 8 > 4
+        ops.minhash(dev(np.zeros(2, np.int64)), dev(np.zeros(0, np.int32)), table16, b=2)
+
+
+# ---------------------------------------------------------------------------- sort
+@pytest.mark.parametrize("n", [0, 1, 63, 4095, 4096, 4097, 70001])
+@pytest.mark.parametrize("nbatch", [1, 3])
+def test_radix_sort_matches_numpy_stable(n, nbatch):
+    rng = np.random.default_rng(n + nbatch)
+    for (lo, hi, bits) in [(0, 64, 64), (0, 24, 20), (32, 56, 64), (8, 16, 64)]:
+        k = rng.integers(0, 2 ** bits, size=(nbatch, n), dtype=np.uint64)
+        v = rng.integers(0, 2 ** 31, size=(nbatch, n), dtype=np.int64).astype(np.int32)
+        ks, vs = ops.sort_u64(dev(k.view(np.int64)), dev(v), lo, hi)
+        torch.cuda.synchronize()
+        mask = np.uint64((1 << (hi - lo)) - 1)
+        for bi in range(nbatch):
+            digit = (k[bi] >> np.uint64(lo)) & mask
+            order = np.argsort(digit, kind="stable")
+            assert np.array_equal(u64(ks)[bi], k[bi][order])
+            assert np.array_equal(vs.cpu().numpy()[bi], v[bi][order])
+        # keys only
+        ks2, none = ops.sort_u64(dev(k.view(np.int64)), None, lo, hi)
+        assert none is None and torch.equal(ks2, ks)
+
+
+def test_mix_sort_groups_equal_keys():
+    rng = np.random.default_rng(0)
+    n, b = 50000, 3
+    k = rng.integers(0, 3000, size=(b, n), dtype=np.uint64) * np.uint64(0x100000001)
+    sk, sid = ops.bucket_sort(dev(k.view(np.int64)))
+    sk, sid = u64(sk), sid.cpu().numpy()
+    mix = np.array([[qrlsh._lib.load().qrlsh_mix64_host(int(x)) >> 32 for x in row] for row in sk[:, :2000]])
+    assert np.all(np.diff(mix.astype(np.int64), axis=1) >= 0)
+    for bi in range(b):
+        assert np.array_equal(k[bi][sid[bi]], sk[bi])
+        same = sk[bi][1:] == sk[bi][:-1]
+        assert np.all(sid[bi][1:][same] > sid[bi][:-1][same])
+        # every key forms exactly one run
+        nruns = 1 + np.count_nonzero(~same)
+        assert nruns == len(np.unique(k[bi]))
+
+
+# ---------------------------------------------------------------------------- a3
+@pytest.mark.parametrize("name", FULL + PIECES)
+def test_candidates_match_reference_golden(name):
+    from lsh import LSH
+    g = load(name)
+    l = LSH(int(g["b"]))
+    l.compute_buckets_batch(g["sig"])
+    stats = {}
+    arr = l.get_candidates_array(stats)
+    assert np.array_equal(u64(arr), np.sort(pairs_u64(g["pairs"])))
+    assert stats["emitted_pairs"] == O.emitted_pairs(O.band_keys(g["sig"], int(g["b"])), int(g["P"]) // int(g["b"]))
+
+
+def test_lsh_dropin_surface_and_edge_semantics():
+    from lsh import LSH
+    g = load("lsh_edge")
+    sig, b = g["sig"], int(g["b"])
+    l = LSH(b)
+    for s in sig:
+        l.compute_buckets(s)           # one call per query, as recommender.py:173-174 does
+    assert l.counter == len(sig)
+    cands = l.get_candidates(sig)
+    assert isinstance(cands, set)
+    assert sorted(cands) == [tuple(x) for x in g["pairs"].tolist()]
+    assert np.array_equal(l.make_subvecs(sig[2]), g["subvecs_row2"])
+    with pytest.raises(AssertionError):
+        LSH(5).make_subvecs(sig[0])
+    # no state leaks between instances (the reference's class-level buckets do leak)
+    l2 = LSH(b)
+    assert l2.counter == 0 and l2.get_candidates(None) == set()
+    # lazily materialised dict buckets look like the reference's
+    bk = l.buckets
+    assert len(bk) == b and all(isinstance(d, dict) for d in bk)
+    ref = O.naive_candidates(sig, b)
+    from itertools import combinations
+    mine = set()
+    for d in bk:
+        for key, hits in d.items():
+            if len(hits) > 1 and set(key.split(",")) != {"-1"}:
+                mine.update(combinations(hits, 2))
+    assert mine == ref
+
+
+def test_duplicate_heavy_bucket():
+    # 300 identical queries: every band has a bucket of 300 -> 44850 pairs, 32x duplicated
+    sig = np.tile(np.arange(128, dtype=np.int32)[None, :], (300, 1))
+    extra = np.random.default_rng(1).integers(0, 30000, size=(100, 128)).astype(np.int32)
+    allsig = np.concatenate([extra[:50], sig, extra[50:]])
+    keys = ops.band_keys(dev(allsig), 32)
+    st = {}
+    pairs = ops.candidate_pairs(keys, 4, st)
+    ref = O.candidates(O.band_keys(allsig, 32), 4)
+    assert np.array_equal(u64(pairs), ref)
+    assert len(ref) == 300 * 299 // 2 and st["emitted_pairs"] == 32 * len(ref)
+
+
+# ---------------------------------------------------------------------------- a5
+@pytest.mark.parametrize("name", FULL + PIECES)
+def test_scores_match_reference_rounding(name):
+    g = load(name)
+    sig = dev(g["sig"])
+    pairs = dev(pairs_u64(g["pairs"]).view(np.int64))
+    norm2 = ops.row_norms(sig)
+    milli, cosv, _ = ops.score_pairs(sig, norm2, pairs, want_cos=True)
+    # np.around(x, 3) == rint(x * 1000) / 1000
+    assert np.array_equal(milli.cpu().numpy() / 1000.0, g["pair_cos"])
+    m_ref, c_ref = O.score_pairs(g["sig"], pairs_u64(g["pairs"]), mode=1, want_cos=True)
+    assert np.array_equal(milli.cpu().numpy(), m_ref)
+    assert np.array_equal(cosv.cpu().numpy(), c_ref)  # same correctly-rounded fp64 formula
+
+
+def test_score_non_multiple_of_4_and_zero_rows():
+    rng = np.random.default_rng(2)
+    sig = rng.integers(-1, 1000, size=(50, 15)).astype(np.int32)
+    sig[7] = 0
+    pairs = np.array([(i << 32) | j for i in range(50) for j in range(i + 1, 50)], dtype=np.uint64)
+    d = dev(sig)
+    milli, _, _ = ops.score_pairs(d, ops.row_norms(d), dev(pairs.view(np.int64)))
+    assert np.array_equal(milli.cpu().numpy(), O.score_pairs(sig, pairs, mode=1))
+    assert np.array_equal(milli.cpu().numpy(), O.score_pairs(sig, pairs, mode=0))
+
+
+@pytest.mark.parametrize("name", FULL)
+def test_full_path_matches_reference_tie_aware(name):
+    g = load(name)
+    P, D, b, K = int(g["P"]), int(g["D"]), int(g["b"]), int(g["K"])
+    table = ops.perm_table(ops.legacy_permutations(P, D, seed=int(g["seed"])), DEV)
+    res = pipeline.query_similarities(dev(g["offsets"]), dev(g["rows"]), table, b, K)
+    torch.cuda.synchronize()
+    assert np.array_equal(res.sig.cpu().numpy(), g["sig"])
+    assert np.array_equal(u64(res.pairs), np.sort(pairs_u64(g["pairs"])))
+    check_topk_tie_aware(g, u64(res.pairs), res.milli.cpu().numpy(), res.src.cpu().numpy(), res.dst.cpu().numpy(),
+                         res.val.cpu().numpy(), K)
+    # and exactly equal to the oracle, which uses the same documented tie-break
+    r = O.query_similarities(g["offsets"], g["rows"], D, P, b, K, int(g["seed"]))
+    assert np.array_equal(res.src.cpu().numpy(), r["src"])
+    assert np.array_equal(res.dst.cpu().numpy(), r["dst"])
+    assert np.array_equal(res.val.cpu().numpy(), r["val"])
+
+
+def test_recommender_dropin_on_generator_default_inputs():
+    """config 1: the CSVs produced by the reference's resources/generator.py, through the
+    drop-in Recommender, under the same np.random.seed as the golden capture."""
+    import pandas as pd
+    import recommender as R
+    g = load("cfg1_hotpath")
+    gdir = os.path.join(GOLDEN, "cfg1")
+    dataset = pd.read_csv(os.path.join(gdir, "dataset.csv"), dtype=str)
+    feats = list(dataset.columns)[1:]
+    qrows, qids = [], []
+    with open(os.path.join(gdir, "queries.csv")) as fh:
+        for line in fh:
+            vals = line.rstrip("\n").split(",")
+            qids.append(vals[0])
+            el = ["" for _ in feats]
+            for v in vals[1:]:
+                a = v.split("=")
+                el[feats.index(a[0])] = a[1]
+            qrows.append(el)
+    rec = R.Recommender()
+    rec.verbose = False
+    rec.datasetFeatures = feats
+    rec.dataset = dataset
+    rec.queries = np.array(qrows, dtype=object)
+    rec.queriesIDs = np.array(qids)
+    rec.tupleCount = {}
+    R.PERM = int(g["P"])
+    off, rows = rec.answer_sets()
+    assert np.array_equal(off, g["offsets"]) and np.array_equal(rows, g["rows"])
+    np.random.seed(int(g["seed"]))
+    sig = rec.compute_signatures()
+    assert sig.dtype == np.int64 and np.array_equal(sig, g["sig"])
+    np.random.seed(int(g["seed"]))
+    qs = rec.compute_querySimilarities()
+    assert sorted(qs.keys()) == sorted(int(q) for q in g["qs_q"])
+    res = rec.last_result
+    assert res.b == int(g["b"]) and res.K == int(g["K"])
+    check_topk_tie_aware(g, u64(res.pairs), res.milli.cpu().numpy(), res.src.cpu().numpy(), res.dst.cpu().numpy(),
+                         res.val.cpu().numpy(), int(g["K"]))
+    for q, e in qs.items():
+        assert e["indexes"].dtype == np.int64 and e["values"].dtype == np.float64
+    R.PERM = 128
+    with pytest.raises(ValueError):
+        rec._band_rule()
+    R.PERM = 180
+
+
+# ---------------------------------------------------------------------------- synthetic + sizes
+def test_synth_generator_matches_oracle_twin():
+    for (nq, D, q0, nl) in [(5000, 32768, 0, None), (5000, 100000, 1234, 777), (64, 50, 0, None)]:
+        off, rows = qrlsh.synth_csr(nq, D, seed=5, q0=q0, nq_local=nl, device=DEV)
+        roff, rrows = O.synth_csr(nq, D, seed=5, q0=q0, nq_local=nl)
+        assert np.array_equal(off.cpu().numpy(), roff)
+        assert np.array_equal(rows.cpu().numpy(), rrows)
+
+
+@pytest.mark.parametrize("nq,D,P,b", [(20000, 32768, 128, 32), (30000, 100000, 128, 32), (12000, 32768, 256, 64),
+                                      (200000, 32768, 128, 32)])
+def test_pipeline_equals_oracle_on_synthetic(nq, D, P, b):
+    K = pipeline.max_candidates(nq)
+    off, rows = qrlsh.synth_csr(nq, D, seed=0, device=DEV)
+    perms = ops.legacy_permutations(P, D, seed=42)
+    res = pipeline.query_similarities(off, rows, ops.perm_table(perms, DEV), b, K)
+    torch.cuda.synchronize()
+    ho, hr = off.cpu().numpy(), rows.cpu().numpy()
+    sig = O.minhash(ho, hr, perms)
+    assert np.array_equal(res.sig.cpu().numpy(), sig)
+    pairs = O.candidates(O.band_keys(sig, b), P // b)
+    assert np.array_equal(u64(res.pairs), pairs)
+    milli = O.score_pairs(sig, pairs, mode=1)
+    assert np.array_equal(res.milli.cpu().numpy(), milli)
+    s, d, v = O.topk(pairs, milli, K)
+    assert np.array_equal(res.src.cpu().numpy(), s)
+    assert np.array_equal(res.dst.cpu().numpy(), d)
+    assert np.array_equal(res.val.cpu().numpy(), v)
+
+
+def test_full_size_config2_properties_and_oracle():
+    """BASELINE config 2 (1 M queries, P=128, b=32): exact equality with the oracle for the
+    integer stages (it finishes in seconds on the box's host cores) plus size-independent
+    properties of the outputs."""
+    nq, D, P, b = 1_000_000, 32768, 128, 32
+    K = pipeline.max_candidates(nq)
+    off, rows = qrlsh.synth_csr(nq, D, seed=0, device=DEV)
+    perms = ops.legacy_permutations(P, D, seed=42)
+    res = pipeline.query_similarities(off, rows, ops.perm_table(perms, DEV), b, K)
+    torch.cuda.synchronize()
+    pairs = u64(res.pairs)
+    i, j = (pairs >> np.uint64(32)).astype(np.int64), (pairs & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    assert np.all(i < j) and j.max() < nq
+    assert np.all(pairs[1:] > pairs[:-1])                       # sorted, unique
+    src, dst, val = res.src.cpu().numpy(), res.dst.cpu().numpy(), res.val.cpu().numpy()
+    key = (src.astype(np.int64) << 32) | (1000 - val).astype(np.int64) << 21 | dst
+    assert np.all(key[1:] > key[:-1])                           # (src, value desc, dst asc), no repeats
+    assert np.bincount(src).max() <= K
+    assert val.min() >= -1000 and val.max() <= 1000
+    # every kept edge is a candidate pair
+    ek = (np.minimum(src, dst).astype(np.uint64) << np.uint64(32)) | np.maximum(src, dst).astype(np.uint64)
+    assert np.all(np.isin(ek[::97], pairs))
+    # oracle, exact
+    ho, hr = off.cpu().numpy(), rows.cpu().numpy()
+    sig = O.minhash(ho, hr, perms)
+    assert np.array_equal(res.sig.cpu().numpy(), sig)
+    opairs = O.candidates(O.band_keys(sig, b), P // b)
+    assert np.array_equal(pairs, opairs)
+    assert np.array_equal(res.milli.cpu().numpy(), O.score_pairs(sig, opairs, mode=1))
