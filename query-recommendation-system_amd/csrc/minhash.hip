@@ -207,7 +207,7 @@ QRLSH_EXPORT int qrlsh_minhash(const int64_t *offsets, const int32_t *rows, int6
                                int64_t *norm2_out, uint64_t *keys_out, int32_t b, void *stream) {
   QR_CHECK_ARG(nq >= 0 && P > 0 && D > 0 && P_stride >= P, "qrlsh_minhash: bad sizes nq=%lld P=%d P_stride=%d D=%d",
                (long long)nq, P, P_stride, D);
-  QR_CHECK_ARG(offsets && perm_t && sig_out, "qrlsh_minhash: null pointer");
+  QR_CHECK_ARG(nq == 0 || (offsets && perm_t && sig_out), "qrlsh_minhash: null pointer");
   QR_CHECK_ARG(perm_dtype == QRLSH_PERM_U16 || perm_dtype == QRLSH_PERM_I32, "qrlsh_minhash: bad perm_dtype %d",
                perm_dtype);
   const int esz = perm_dtype == QRLSH_PERM_U16 ? 2 : 4;
@@ -233,7 +233,7 @@ QRLSH_EXPORT int qrlsh_minhash(const int64_t *offsets, const int32_t *rows, int6
 
 QRLSH_EXPORT int qrlsh_band_keys(const int32_t *sig, int64_t nq, int32_t P, int32_t b, uint64_t *keys_out,
                                  int64_t *norm2_out, void *stream) {
-  QR_CHECK_ARG(sig && keys_out && nq >= 0 && P > 0, "qrlsh_band_keys: bad arguments");
+  QR_CHECK_ARG(nq >= 0 && P > 0 && (nq == 0 || (sig && keys_out)), "qrlsh_band_keys: bad arguments");
   QR_CHECK_ARG(b > 0 && P % b == 0, "qrlsh_band_keys: signature length %d not divisible by b=%d", P, b);
   const int r = P / b;
   if (r > 4) {
@@ -251,7 +251,7 @@ QRLSH_EXPORT int qrlsh_band_keys(const int32_t *sig, int64_t nq, int32_t P, int3
 }
 
 QRLSH_EXPORT int qrlsh_row_norms(const int32_t *sig, int64_t nq, int32_t P, int64_t *norm2_out, void *stream) {
-  QR_CHECK_ARG(sig && norm2_out && nq >= 0 && P > 0, "qrlsh_row_norms: bad arguments");
+  QR_CHECK_ARG(nq >= 0 && P > 0 && (nq == 0 || (sig && norm2_out)), "qrlsh_row_norms: bad arguments");
   if (nq == 0) return QRLSH_OK;
   const int64_t blocks = ceil_div64(nq, 4);
   QR_LAUNCH("row_norms", row_norms_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0,
