@@ -39,7 +39,8 @@ def parse():
     ap.add_argument("--perm", type=int, default=128)
     ap.add_argument("--bands", type=int, default=32)
     ap.add_argument("--drows", type=int, default=32768)
-    ap.add_argument("--cpu-sample", type=int, default=100_000, help="queries in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="queries in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="OpenMP threads of the CPU baseline (box share: 16/GPU)")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
     return ap.parse_args()
 
@@ -168,7 +169,7 @@ def main():
         cpu_baseline = None
         recall = None
         if args.cpu_sample > 0:
-            cpu_baseline, recall = cpu_leg(args.cpu_sample, D, P, b, dev)
+            cpu_baseline, recall = cpu_leg(args.cpu_sample, D, P, b, dev, args.cpu_threads)
 
         out = {
             "metric": "MinHash signatures/sec through the whole hot path (signatures -> LSH candidates -> pair scoring -> top-K)",
@@ -202,7 +203,7 @@ def main():
         print(json.dumps(out))
 
 
-def cpu_leg(nq_s, D, P, b, dev):
+def cpu_leg(nq_s, D, P, b, dev, threads):
     """CPU baseline (oracle = a C port of the reference's algorithm, OpenMP) on a bounded
     sample of the same workload, and recall@10 of the GPU path against it."""
     import qrlsh
@@ -214,7 +215,12 @@ def cpu_leg(nq_s, D, P, b, dev):
     K = pipeline.max_candidates(nq_s)
     perms = ops.legacy_permutations(P, D, seed=42)
     ho, hr = O.synth_csr(nq_s, D, seed=0)
-    cores = O.max_threads()
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(threads, avail))
+    O.set_threads(cores)
     O.query_similarities(ho[:2001], hr[:ho[2000]], D, P, b, K, 42)  # warm the library / threads
     t0 = time.perf_counter()
     sig = O.minhash(ho, hr, perms)

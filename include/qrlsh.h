@@ -87,7 +87,8 @@ int qrlsh_sort_u64(uint64_t *keys_a, uint64_t *keys_b, uint32_t *vals_a, uint32_
 
 /* ---- a3: candidate pairs -------------------------------------------------------
  * Replaces LSH.get_candidates, lsh.py:40-55.  Input: per band, keys sorted with
- * QRLSH_SORT_MIX over 32 bits and their query ids ([b][nq] each).  Every run of
+ * QRLSH_SORT_MIX over the top hash_bits (8..32) bits of mix64(key), i.e. bits
+ * [64 - hash_bits, 64), and their query ids ([b][nq] each).  Every run of
  * equal keys that is not the all -1 tuple (:47) yields all its (i < j) pairs (:49).
  * pairs are i << 32 | j; duplicates across bands are still present (the Python
  * set's job, :41) -- sort them and call qrlsh_unique_*.
@@ -95,10 +96,11 @@ int qrlsh_sort_u64(uint64_t *keys_a, uint64_t *keys_b, uint32_t *vals_a, uint32_
  *   fill : writes exactly that many pairs (capacity checked by the caller)
  */
 size_t qrlsh_pairs_workspace_bytes(int64_t nq, int32_t b);
-int qrlsh_pairs_count(const uint64_t *sorted_keys, int64_t nq, int32_t b, int32_t r, void *workspace,
-                      size_t workspace_bytes, uint64_t *total_out, void *stream);
+int qrlsh_pairs_count(const uint64_t *sorted_keys, int64_t nq, int32_t b, int32_t r, int32_t hash_bits,
+                      void *workspace, size_t workspace_bytes, uint64_t *total_out, void *stream);
 int qrlsh_pairs_fill(const uint64_t *sorted_keys, const uint32_t *sorted_ids, int64_t nq, int32_t b,
-                     int32_t r, const void *workspace, uint64_t *pairs_out, void *stream);
+                     int32_t r, int32_t hash_bits, const void *workspace, uint64_t *pairs_out,
+                     void *stream);
 
 /* unique of a sorted uint64 array (count-then-fill) */
 size_t qrlsh_compact_workspace_bytes(int64_t n);

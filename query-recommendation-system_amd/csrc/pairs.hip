@@ -19,24 +19,24 @@ constexpr int CMP_THREADS = 256;
 constexpr int CMP_IPT = 8;
 constexpr int CMP_TILE = CMP_THREADS * CMP_IPT;
 
-__device__ static inline uint32_t mix_hi(uint64_t k) { return (uint32_t)(qr_mix64(k) >> 32); }
+__device__ static inline uint32_t mix_hi(uint64_t k, int hsh) { return (uint32_t)(qr_mix64(k) >> hsh); }
 
 // number of earlier records in the same run with an identical key
-__device__ static inline uint32_t count_back(const uint64_t *__restrict__ k, int64_t t, uint64_t ek) {
+__device__ static inline uint32_t count_back(const uint64_t *__restrict__ k, int64_t t, uint64_t ek, int hsh) {
   const uint64_t kt = k[t];
   if (kt == ek) return 0;
-  const uint32_t ht = mix_hi(kt);
+  const uint32_t ht = mix_hi(kt, hsh);
   uint32_t c = 0;
   for (int64_t u = t - 1; u >= 0; --u) {
     const uint64_t ku = k[u];
     if (ku == kt) ++c;
-    else if (mix_hi(ku) != ht) break;
+    else if (mix_hi(ku, hsh) != ht) break;
   }
   return c;
 }
 
 __global__ __launch_bounds__(PAIR_THREADS) void pairs_count_kernel(const uint64_t *__restrict__ keys, int64_t nq,
-                                                                   int ntiles, uint64_t ek,
+                                                                   int ntiles, uint64_t ek, int hsh,
                                                                    uint64_t *__restrict__ blk) {
   __shared__ uint64_t sm[4];
   const int tile = blockIdx.x, band = blockIdx.y;
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void pairs_count_kernel(const uint64_
   uint64_t c = 0;
 #pragma unroll
   for (int i = 0; i < PAIR_IPT; ++i)
-    if (t0 + i < nq) c += count_back(k, t0 + i, ek);
+    if (t0 + i < nq) c += count_back(k, t0 + i, ek, hsh);
   uint64_t total;
   (void)block_excl_scan_u64_256(c, sm, &total);
   if (threadIdx.x == 0) blk[(size_t)band * ntiles + tile] = total;
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void pairs_count_kernel(const uint64_
 
 __global__ __launch_bounds__(PAIR_THREADS) void pairs_fill_kernel(const uint64_t *__restrict__ keys,
                                                                   const uint32_t *__restrict__ ids, int64_t nq,
-                                                                  int ntiles, uint64_t ek,
+                                                                  int ntiles, uint64_t ek, int hsh,
                                                                   const uint64_t *__restrict__ blk,
                                                                   uint64_t *__restrict__ out) {
   __shared__ uint64_t sm[4];
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void pairs_fill_kernel(const uint64_t
   uint64_t mine = 0;
 #pragma unroll
   for (int i = 0; i < PAIR_IPT; ++i) {
-    c[i] = (t0 + i < nq) ? count_back(k, t0 + i, ek) : 0;
+    c[i] = (t0 + i < nq) ? count_back(k, t0 + i, ek, hsh) : 0;
     mine += c[i];
   }
   uint64_t total;
@@ -180,10 +180,12 @@ QRLSH_EXPORT size_t qrlsh_pairs_workspace_bytes(int64_t nq, int32_t b) {
   return (size_t)b * ceil_div64(nq, PAIR_TILE) * sizeof(uint64_t);
 }
 
-QRLSH_EXPORT int qrlsh_pairs_count(const uint64_t *sorted_keys, int64_t nq, int32_t b, int32_t r, void *workspace,
+QRLSH_EXPORT int qrlsh_pairs_count(const uint64_t *sorted_keys, int64_t nq, int32_t b, int32_t r, int32_t hash_bits,
+                                   void *workspace,
                                    size_t workspace_bytes, uint64_t *total_out, void *stream) {
   QR_CHECK_ARG(nq >= 0 && b > 0 && r > 0 && r <= 4, "qrlsh_pairs_count: bad sizes nq=%lld b=%d r=%d", (long long)nq,
                b, r);
+  QR_CHECK_ARG(hash_bits >= 8 && hash_bits <= 32, "qrlsh_pairs_count: hash_bits=%d not in [8,32]", hash_bits);
   QR_CHECK_ARG(total_out && workspace, "qrlsh_pairs_count: null pointer");
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (nq == 0) {
@@ -202,20 +204,22 @@ QRLSH_EXPORT int qrlsh_pairs_count(const uint64_t *sorted_keys, int64_t nq, int3
   const int ntiles = (int)ceil_div64(nq, PAIR_TILE);
   uint64_t *blk = static_cast<uint64_t *>(workspace);
   QR_LAUNCH("pairs_count", pairs_count_kernel, dim3(ntiles, b), dim3(PAIR_THREADS), 0, st, sorted_keys, nq, ntiles,
-                     qr_empty_key(r), blk);
+                     qr_empty_key(r), 64 - hash_bits, blk);
   QR_LAUNCH("scan_blocks", scan_u64_kernel, dim3(1), dim3(1024), 0, st, blk, (int64_t)ntiles * b, total_out);
   QR_LAUNCH_CHECK("qrlsh_pairs_count");
   return QRLSH_OK;
 }
 
 QRLSH_EXPORT int qrlsh_pairs_fill(const uint64_t *sorted_keys, const uint32_t *sorted_ids, int64_t nq, int32_t b,
-                                  int32_t r, const void *workspace, uint64_t *pairs_out, void *stream) {
-  QR_CHECK_ARG(nq >= 0 && b > 0 && r > 0 && r <= 4, "qrlsh_pairs_fill: bad sizes");
+                                  int32_t r, int32_t hash_bits, const void *workspace, uint64_t *pairs_out,
+                                  void *stream) {
+  QR_CHECK_ARG(nq >= 0 && b > 0 && r > 0 && r <= 4 && hash_bits >= 8 && hash_bits <= 32, "qrlsh_pairs_fill: bad sizes");
   if (nq == 0) return QRLSH_OK;
   QR_CHECK_ARG(sorted_keys && sorted_ids && workspace && pairs_out, "qrlsh_pairs_fill: null pointer");
   const int ntiles = (int)ceil_div64(nq, PAIR_TILE);
   QR_LAUNCH("pairs_fill", pairs_fill_kernel, dim3(ntiles, b), dim3(PAIR_THREADS), 0, static_cast<hipStream_t>(stream),
-                     sorted_keys, sorted_ids, nq, ntiles, qr_empty_key(r), static_cast<const uint64_t *>(workspace),
+                     sorted_keys, sorted_ids, nq, ntiles, qr_empty_key(r), 64 - hash_bits,
+                     static_cast<const uint64_t *>(workspace),
                      pairs_out);
   QR_LAUNCH_CHECK("qrlsh_pairs_fill");
   return QRLSH_OK;

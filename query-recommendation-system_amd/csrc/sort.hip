@@ -43,31 +43,39 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const uint64_t 
   ghist[((size_t)batch * RADIX + threadIdx.x) * ntiles + tile] = h[threadIdx.x];
 }
 
-// exclusive scan of m uint32 per batch, one workgroup (1024 threads) per batch
-__global__ __launch_bounds__(1024) void sort_scan_kernel(uint32_t *__restrict__ ghist, int m) {
-  __shared__ uint32_t wsum[16];
-  uint32_t *a = ghist + (size_t)blockIdx.x * m;
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int per = (m + 1023) / 1024;
-  const int lo = min(t * per, m), hi = min(lo + per, m);
-  uint32_t s = 0;
-  for (int i = lo; i < hi; ++i) s += a[i];
-  uint32_t inc = s;
+// One workgroup per (digit, batch) row of ghist: exclusive scan of the row's ntiles tile
+// counts in place, and the row total to rtot[batch][digit].  The scatter kernel turns the
+// 256 row totals into digit bases itself, so a pass needs no single-workgroup scan.
+__global__ __launch_bounds__(256) void sort_rowscan_kernel(uint32_t *__restrict__ ghist, int ntiles,
+                                                           uint32_t *__restrict__ rtot) {
+  __shared__ uint32_t wsum[4];
+  const int d = blockIdx.x, batch = blockIdx.y;
+  uint32_t *row = ghist + ((size_t)batch * RADIX + d) * ntiles;
+  const int t = threadIdx.x, lane = t & (WAVE - 1), w = t >> 6;
+  uint32_t carry = 0;
+  for (int base = 0; base < ntiles; base += 256) {
+    const int i = base + t;
+    const uint32_t v = i < ntiles ? row[i] : 0;
+    uint32_t inc = v;
 #pragma unroll
-  for (int d = 1; d < WAVE; d <<= 1) {
-    uint32_t o = __shfl_up(inc, d, WAVE);
-    if (lane >= d) inc += o;
+    for (int k = 1; k < WAVE; k <<= 1) {
+      const uint32_t o = __shfl_up(inc, k, WAVE);
+      if (lane >= k) inc += o;
+    }
+    if (lane == WAVE - 1) wsum[w] = inc;
+    __syncthreads();
+    uint32_t wbase = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t x = wsum[k];
+      if (k < w) wbase += x;
+      tot += x;
+    }
+    if (i < ntiles) row[i] = carry + wbase + inc - v;
+    carry += tot;
+    __syncthreads();
   }
-  if (lane == WAVE - 1) wsum[w] = inc;
-  __syncthreads();
-  uint32_t base = 0;
-  for (int i = 0; i < w; ++i) base += wsum[i];
-  uint32_t run = base + inc - s;
-  for (int i = lo; i < hi; ++i) {
-    const uint32_t v = a[i];
-    a[i] = run;
-    run += v;
-  }
+  if (t == 0) rtot[(size_t)batch * RADIX + d] = carry;
 }
 
 template <bool MIX, bool HAS_VAL, bool IOTA>
@@ -76,8 +84,10 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const uint64
                                                                     uint64_t *__restrict__ keys_out,
                                                                     uint32_t *__restrict__ vals_out, int64_t n,
                                                                     int ntiles, int shift,
-                                                                    const uint32_t *__restrict__ goff) {
+                                                                    const uint32_t *__restrict__ goff,
+                                                                    const uint32_t *__restrict__ rtot) {
   __shared__ uint32_t cnt[SORT_THREADS / WAVE][RADIX];
+  __shared__ uint32_t dsum[SORT_THREADS / WAVE];
   const int tile = blockIdx.x, batch = blockIdx.y;
   const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x >> 6;
 #pragma unroll
@@ -122,7 +132,21 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const uint64
   {
     // chain the waves: cnt[w][d] becomes the global position of wave w's first key with digit d
     const int d = threadIdx.x;
-    uint32_t run = goff[((size_t)batch * RADIX + d) * ntiles + tile];
+    // digit base = exclusive prefix of the 256 row totals of this batch
+    const uint32_t tot = rtot[(size_t)batch * RADIX + d];
+    uint32_t inc = tot;
+#pragma unroll
+    for (int k = 1; k < WAVE; k <<= 1) {
+      const uint32_t o = __shfl_up(inc, k, WAVE);
+      if (lane >= k) inc += o;
+    }
+    if (lane == WAVE - 1) dsum[w] = inc;
+    __syncthreads();
+    uint32_t dbase = inc - tot;
+#pragma unroll
+    for (int k = 0; k < SORT_THREADS / WAVE; ++k)
+      if (k < w) dbase += dsum[k];
+    uint32_t run = dbase + goff[((size_t)batch * RADIX + d) * ntiles + tile];
 #pragma unroll
     for (int i = 0; i < SORT_THREADS / WAVE; ++i) {
       const uint32_t c = cnt[i][d];
@@ -146,7 +170,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const uint64
 QRLSH_EXPORT size_t qrlsh_sort_workspace_bytes(int64_t n, int32_t nbatch) {
   if (n <= 0 || nbatch <= 0) return 16;
   const int64_t ntiles = ceil_div64(n, SORT_TILE);
-  return (size_t)nbatch * RADIX * ntiles * sizeof(uint32_t);
+  return (size_t)nbatch * RADIX * (ntiles + 1) * sizeof(uint32_t);
 }
 
 template <bool MIX>
@@ -155,21 +179,22 @@ static int sort_passes(uint64_t *ka, uint64_t *kb, uint32_t *va, uint32_t *vb, i
   const int ntiles = (int)ceil_div64(n, SORT_TILE);
   const dim3 grid(ntiles, nbatch), block(SORT_THREADS);
   const bool has_val = va != nullptr;
+  uint32_t *rtot = ghist + (size_t)nbatch * RADIX * ntiles;
   int cur = 0;
   for (int shift = bit_lo; shift < bit_hi; shift += 8) {
     uint64_t *kin = cur ? kb : ka, *kout = cur ? ka : kb;
     uint32_t *vin = cur ? vb : va, *vout = cur ? va : vb;
     QR_LAUNCH("sort_hist", (sort_hist_kernel<MIX>), grid, block, 0, st, kin, n, ntiles, shift, ghist);
-    QR_LAUNCH("sort_scan", sort_scan_kernel, dim3(nbatch), dim3(1024), 0, st, ghist, RADIX * ntiles);
+    QR_LAUNCH("sort_rowscan", sort_rowscan_kernel, dim3(RADIX, nbatch), dim3(256), 0, st, ghist, ntiles, rtot);
     if (!has_val)
       QR_LAUNCH("sort_scatter_k", (sort_scatter_kernel<MIX, false, false>), grid, block, 0, st, kin, vin, kout, vout, n,
-                         ntiles, shift, ghist);
+                         ntiles, shift, ghist, rtot);
     else if (iota && shift == bit_lo)
       QR_LAUNCH("sort_scatter_kv", (sort_scatter_kernel<MIX, true, true>), grid, block, 0, st, kin, vin, kout, vout, n,
-                         ntiles, shift, ghist);
+                         ntiles, shift, ghist, rtot);
     else
       QR_LAUNCH("sort_scatter_kv", (sort_scatter_kernel<MIX, true, false>), grid, block, 0, st, kin, vin, kout, vout, n,
-                         ntiles, shift, ghist);
+                         ntiles, shift, ghist, rtot);
     cur ^= 1;
   }
   hipError_t e = hipGetLastError();

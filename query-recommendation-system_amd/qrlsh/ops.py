@@ -173,18 +173,26 @@ def sort_u64(keys, vals=None, bit_lo=0, bit_hi=64, mix=False, iota=False):
     return ko, vo
 
 
-def bucket_sort(keys):
+def hash_bits_for(n):
+    """Bits of mix64(key) the grouping sort orders by: enough that a run of equal hash bits
+    holds ~1/8 foreign keys on average (n / 2^bits <= 1/8), in whole 8-bit passes."""
+    need = max(1, int(n - 1).bit_length()) + 3 if n > 1 else 8
+    return min(32, max(8, (need + 7) // 8 * 8))
+
+
+def bucket_sort(keys, hash_bits=None):
     """Group equal band keys (replaces the dict buckets of lsh.py:31-38): per band, sort
-    (key, query id) by the top 32 bits of mix64(key).  keys int64 [b,nq] (consumed).
+    (key, query id) by the top hash_bits bits of mix64(key).  keys int64 [b,nq] (consumed).
     Returns (sorted_keys [b,nq], sorted_ids int32 [b,nq])."""
     _need(keys, torch.int64, "keys", 2)
-    return sort_u64(keys, None, 32, 64, mix=True, iota=True)
+    hb = hash_bits if hash_bits is not None else hash_bits_for(keys.shape[1])
+    return sort_u64(keys, None, 64 - hb, 64, mix=True, iota=True)
 
 
 # ---------------------------------------------------------------------------
 # a3: pairs
 # ---------------------------------------------------------------------------
-def emit_pairs(sorted_keys, sorted_ids, r):
+def emit_pairs(sorted_keys, sorted_ids, r, hash_bits=None):
     """All (i<j) pairs of every non-empty bucket with > 1 member, every band
     (lsh.py:42-53), as int64 i<<32|j, duplicates across bands included."""
     lib = _lib.load()
@@ -192,13 +200,14 @@ def emit_pairs(sorted_keys, sorted_ids, r):
     _need(sorted_ids, torch.int32, "sorted_ids", 2)
     b, nq = sorted_keys.shape
     dev = sorted_keys.device
+    hb = hash_bits if hash_bits is not None else hash_bits_for(nq)
     ws = _ws(lib.qrlsh_pairs_workspace_bytes(nq, b), dev)
     total = torch.zeros(1, dtype=torch.int64, device=dev)
-    _lib.check(lib.qrlsh_pairs_count(_ptr(sorted_keys), nq, b, r, _ptr(ws), ws.numel(), _ptr(total), _stream()))
+    _lib.check(lib.qrlsh_pairs_count(_ptr(sorted_keys), nq, b, r, hb, _ptr(ws), ws.numel(), _ptr(total), _stream()))
     n = int(total.item())
     pairs = torch.empty((n,), dtype=torch.int64, device=dev)
     if n:
-        _lib.check(lib.qrlsh_pairs_fill(_ptr(sorted_keys), _ptr(sorted_ids), nq, b, r, _ptr(ws), _ptr(pairs),
+        _lib.check(lib.qrlsh_pairs_fill(_ptr(sorted_keys), _ptr(sorted_ids), nq, b, r, hb, _ptr(ws), _ptr(pairs),
                                         _stream()))
     return pairs
 

@@ -99,7 +99,7 @@ def test_mix_sort_groups_equal_keys():
     rng = np.random.default_rng(0)
     n, b = 50000, 3
     k = rng.integers(0, 3000, size=(b, n), dtype=np.uint64) * np.uint64(0x100000001)
-    sk, sid = ops.bucket_sort(dev(k.view(np.int64)))
+    sk, sid = ops.bucket_sort(dev(k.view(np.int64)), hash_bits=32)
     sk, sid = u64(sk), sid.cpu().numpy()
     mix = np.array([[qrlsh._lib.load().qrlsh_mix64_host(int(x)) >> 32 for x in row] for row in sk[:, :2000]])
     assert np.all(np.diff(mix.astype(np.int64), axis=1) >= 0)
