@@ -1,0 +1,198 @@
+"""Query-sharded hot path over one process per GPU (torch.distributed; backend "nccl" = RCCL
+over xGMI on the GPU box, "gloo" in the CPU tests).
+
+Rank g owns the contiguous query range [g*nql, (g+1)*nql) and bands {k : k // ceil(b/W) == g}.
+
+  1. MinHash + band keys + norms on the local shard (no communication).
+  2. signature rows and norms start an ASYNC all-gather (they are only needed for scoring,
+     so the transfer hides behind steps 3-6).
+  3. bucket-id exchange so that cross-shard candidates are found.  Two modes with identical
+     results:
+       "all_to_all" (default): band-partitioned -- a rank receives only the bands it owns,
+                     b/W * nq_total * 8 bytes instead of b * nq_total * 8;
+       "all_gather": every rank receives every band key (the exchange BASELINE.json's
+                     north_star names), then keeps its bands.
+  4. per owned band: bucket sort + pair emission over ALL queries; local sort + unique.
+  5. pairs go to the owner of their smaller query id (variable-size all-to-all); the owner
+     sorts + uniques what it received -> its share of the global candidate set.
+  6. owners score their pairs against the gathered signatures; the reverse edge (j -> i) of
+     every scored pair goes to the owner of j (variable-size all-to-all).
+  7. per-query top-K on the local edges.
+
+The compute steps go through a small backend object so that the host logic above can be
+exercised on CPU (gloo) with the oracle standing in for the kernels (tests only); the
+default backend is the HIP library and nothing else ships.
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .pipeline import HotPathResult
+
+
+class HipBackend:
+    """libqrlsh kernels (the product path)."""
+
+    def minhash(self, offsets, rows, table, b):
+        return ops.minhash(offsets, rows, table, b=b, want_norm=True)
+
+    def emit_pairs(self, keys, r):
+        sk, sid = ops.bucket_sort(keys)
+        return ops.emit_pairs(sk, sid, r)
+
+    def sort_unique(self, words, bit_ranges):
+        for lo, hi in bit_ranges:
+            words, _ = ops.sort_u64(words, None, lo, hi)
+        return ops.unique_sorted(words)
+
+    def sort_words(self, words, lo, hi):
+        return ops.sort_u64(words, None, lo, hi)[0]
+
+    def score(self, sig_all, norm_all, pairs, id_bits):
+        milli, _, edges = ops.score_pairs(sig_all, norm_all, pairs, edge_id_bits=id_bits)
+        return milli, edges
+
+    def topk(self, edges, K, id_bits):
+        return ops.topk_edges(edges, K, id_bits)
+
+
+def band_owner_ranges(b, world):
+    """contiguous band blocks: rank g owns [lo[g], hi[g])"""
+    per = (b + world - 1) // world
+    return [(min(g * per, b), min((g + 1) * per, b)) for g in range(world)]
+
+
+class _Done:
+    def wait(self):
+        return None
+
+
+def _staged(t, group):
+    """gloo cannot move device tensors through every collective: stage them through the host.
+    Only used by tests that run several gloo ranks on one GPU; RCCL never takes this path."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def _all_gather(out, inp, group=None, async_op=False):
+    if _staged(inp, group):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(o, inp.cpu(), group=group)
+        out.copy_(o)
+        return _Done()
+    h = dist.all_gather_into_tensor(out, inp, group=group, async_op=async_op)
+    return h if async_op else _Done()
+
+
+def _all_to_all(out, inp, osplit=None, isplit=None, group=None):
+    if _staged(inp, group):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu(), output_split_sizes=osplit, input_split_sizes=isplit, group=group)
+        out.copy_(o)
+        return
+    dist.all_to_all_single(out, inp, output_split_sizes=osplit, input_split_sizes=isplit, group=group)
+
+
+def _exchange_var(chunks_sizes, send, group=None):
+    """variable-size all-to-all of a 1-D int64 tensor already ordered by destination.
+    chunks_sizes: python list of per-destination element counts."""
+    world = dist.get_world_size(group)
+    dev = send.device
+    sizes = torch.tensor(chunks_sizes, dtype=torch.int64, device=dev)
+    rsizes = torch.empty(world, dtype=torch.int64, device=dev)
+    _all_to_all(rsizes, sizes, group=group)
+    rs = rsizes.tolist()
+    recv = torch.empty(int(sum(rs)), dtype=send.dtype, device=dev)
+    _all_to_all(recv, send, rs, list(chunks_sizes), group)
+    return recv
+
+
+def _split_by_bounds(sorted_words, bounds):
+    """sizes of the W consecutive chunks of sorted_words delimited by the W-1 `bounds` values"""
+    if len(bounds) == 0:
+        return [int(sorted_words.numel())]
+    bt = torch.tensor(bounds, dtype=torch.int64, device=sorted_words.device)
+    cut = torch.searchsorted(sorted_words, bt).tolist()
+    edges = [0] + cut + [int(sorted_words.numel())]
+    return [edges[i + 1] - edges[i] for i in range(len(edges) - 1)]
+
+
+def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="all_to_all", backend=None,
+                               group=None):
+    """Hot path for this rank's query shard; collective over `group`.  Every rank must hold
+    the same number of queries (nq_total % world == 0).  Returns a HotPathResult whose pairs /
+    top-K rows are this rank's share (global query ids); concatenated over ranks in rank
+    order they equal the single-GPU result."""
+    be = backend if backend is not None else HipBackend()
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    nql = offsets.numel() - 1
+    if nql * world != nq_total:
+        raise ValueError("every rank must own nq_total / world queries (got %d x %d != %d)" % (nql, world, nq_total))
+    P = table.P
+    if P % b != 0:
+        raise AssertionError("signature length %d not divisible by b=%d" % (P, b))
+    r = P // b
+    ib = ops.id_bits_for(nq_total)
+    if 2 * ib + 11 > 64:
+        raise NotImplementedError("nq_total=%d needs %d-bit ids; the top-K key holds 26" % (nq_total, ib))
+    dev = offsets.device
+    stats = {}
+
+    # 1. local signatures
+    sig, norm2, keys = be.minhash(offsets, rows, table, b)
+
+    # 2. async gather of the signature rows + norms (consumed in step 6)
+    sig_all = torch.empty((nq_total, P), dtype=torch.int32, device=dev)
+    norm_all = torch.empty((nq_total,), dtype=torch.int64, device=dev)
+    h_sig = _all_gather(sig_all, sig, group, async_op=True)
+    h_nrm = _all_gather(norm_all, norm2, group, async_op=True)
+
+    # 3. bucket-id exchange
+    ranges = band_owner_ranges(b, world)
+    lo, hi = ranges[rank]
+    nb = hi - lo
+    if exchange == "all_gather":
+        allk = torch.empty((world * b, nql), dtype=torch.int64, device=dev)
+        _all_gather(allk, keys, group)
+        owned = allk.view(world, b, nql)[:, lo:hi, :].permute(1, 0, 2).reshape(nb, nq_total).contiguous()
+        del allk
+    elif exchange == "all_to_all":
+        in_split = [h - l for (l, h) in ranges]
+        recv = torch.empty((world * nb, nql), dtype=torch.int64, device=dev)
+        _all_to_all(recv, keys, [nb] * world, in_split, group)
+        owned = recv.view(world, nb, nql).permute(1, 0, 2).reshape(nb, nq_total).contiguous()
+        del recv
+    else:
+        raise ValueError("exchange must be 'all_to_all' or 'all_gather'")
+    del keys
+
+    # 4. candidates of the owned bands over all queries
+    pair_bits = [(0, ib), (32, 32 + ib)]
+    if nb > 0:
+        emitted = be.emit_pairs(owned, r)
+        stats["emitted_pairs"] = int(emitted.numel())
+        mine = be.sort_unique(emitted, pair_bits) if emitted.numel() else emitted
+    else:
+        stats["emitted_pairs"] = 0
+        mine = torch.empty((0,), dtype=torch.int64, device=dev)
+    del owned
+
+    # 5. pairs -> owner of i
+    bounds = [(g * nql) << 32 for g in range(1, world)]
+    got = _exchange_var(_split_by_bounds(mine, bounds), mine, group)
+    pairs = be.sort_unique(got, pair_bits) if got.numel() else got
+
+    # 6. score on the owner; reverse edges -> owner of j
+    h_sig.wait()
+    h_nrm.wait()
+    milli, edges = be.score(sig_all, norm_all, pairs, ib)
+    fwd = edges[0::2].contiguous()
+    rev = be.sort_words(edges[1::2].contiguous(), ib + 11, 2 * ib + 11) if pairs.numel() else edges[1::2].contiguous()
+    ebounds = [(g * nql) << (ib + 11) for g in range(1, world)]
+    rev_in = _exchange_var(_split_by_bounds(rev, ebounds), rev, group)
+
+    # 7. local top-K
+    src, dst, val = be.topk(torch.cat([fwd, rev_in]), K, ib)
+    stats["unique_pairs"] = int(pairs.numel())
+    stats["kept_edges"] = int(src.numel())
+    return HotPathResult(sig, norm2, pairs, milli, src, dst, val, K, b, stats)

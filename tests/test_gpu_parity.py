@@ -318,3 +318,36 @@ def test_full_size_config2_properties_and_oracle():
     opairs = O.candidates(O.band_keys(sig, b), P // b)
     assert np.array_equal(pairs, opairs)
     assert np.array_equal(res.milli.cpu().numpy(), O.score_pairs(sig, opairs, mode=1))
+
+
+# ---------------------------------------------------------------------------- sharded driver
+def _run_dist_gpu(tmp_path, world, nq, D, P, b, mode, backend, port):
+    import subprocess
+    import sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env["OMP_NUM_THREADS"] = "1"
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [_sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "tests", "dist_gpu_worker.py"),
+           str(tmp_path), str(nq), str(D), str(P), str(b), mode, backend]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    return [np.load(os.path.join(tmp_path, "rank%d.npz" % r)) for r in range(world)]
+
+
+@pytest.mark.parametrize("world,mode,backend", [(1, "all_to_all", "nccl"), (2, "all_to_all", "gloo"),
+                                                (4, "all_gather", "gloo")])
+def test_sharded_driver_on_gpu_equals_single_gpu(tmp_path, world, mode, backend):
+    nq, D, P, b = 40000, 32768, 128, 32
+    outs = _run_dist_gpu(tmp_path, world, nq, D, P, b, mode, backend, 29571 + world)
+    K = pipeline.max_candidates(nq)
+    off, rows = qrlsh.synth_csr(nq, D, seed=0, device=DEV)
+    res = pipeline.query_similarities(off, rows, ops.perm_table(ops.legacy_permutations(P, D, seed=42), DEV), b, K)
+    torch.cuda.synchronize()
+    assert np.array_equal(np.concatenate([o["pairs"] for o in outs]), res.pairs.cpu().numpy())
+    assert np.array_equal(np.concatenate([o["milli"] for o in outs]), res.milli.cpu().numpy())
+    assert np.array_equal(np.concatenate([o["src"] for o in outs]), res.src.cpu().numpy())
+    assert np.array_equal(np.concatenate([o["dst"] for o in outs]), res.dst.cpu().numpy())
+    assert np.array_equal(np.concatenate([o["val"] for o in outs]), res.val.cpu().numpy())
+    assert sum(int(o["emitted"]) for o in outs) == res.stats["emitted_pairs"]
