@@ -19,15 +19,37 @@ constexpr int CMP_THREADS = 256;
 constexpr int CMP_IPT = 8;
 constexpr int CMP_TILE = CMP_THREADS * CMP_IPT;
 
+constexpr int PAIR_HALO = 128;  // records before the tile that are staged in LDS as well
+
 __device__ static inline uint32_t mix_hi(uint64_t k, int hsh) { return (uint32_t)(qr_mix64(k) >> hsh); }
 
-// number of earlier records in the same run with an identical key
-__device__ static inline uint32_t count_back(const uint64_t *__restrict__ k, int64_t t, uint64_t ek, int hsh) {
-  const uint64_t kt = k[t];
+// Stage keys (and their hash-run ids) of [tile_start - HALO, tile_start + TILE) in LDS.
+__device__ static inline void stage_tile(const uint64_t *__restrict__ k, int64_t nq, int64_t tile_start, int hsh,
+                                         uint64_t *sk, uint32_t *sh) {
+  for (int idx = threadIdx.x; idx < PAIR_HALO + PAIR_TILE; idx += PAIR_THREADS) {
+    const int64_t g = tile_start - PAIR_HALO + idx;
+    uint64_t key = 0;
+    if (g >= 0 && g < nq) key = k[g];
+    sk[idx] = key;
+    sh[idx] = mix_hi(key, hsh);
+  }
+}
+
+// Number of earlier records of the same band whose key equals record t's.  The walk runs
+// backwards through the hash-run in LDS; a run longer than the halo continues in global memory.
+__device__ static inline uint32_t count_back(const uint64_t *__restrict__ k, const uint64_t *sk, const uint32_t *sh,
+                                             int64_t tile_start, int tl, uint64_t ek, int hsh) {
+  const uint64_t kt = sk[PAIR_HALO + tl];
   if (kt == ek) return 0;
-  const uint32_t ht = mix_hi(kt, hsh);
+  const uint32_t ht = sh[PAIR_HALO + tl];
   uint32_t c = 0;
-  for (int64_t u = t - 1; u >= 0; --u) {
+  int idx = PAIR_HALO + tl - 1;
+  const int lo = (tile_start >= PAIR_HALO) ? 0 : (int)(PAIR_HALO - tile_start);  // first staged index that exists
+  for (; idx >= lo; --idx) {
+    if (sk[idx] == kt) ++c;
+    else if (sh[idx] != ht) return c;
+  }
+  for (int64_t u = tile_start - PAIR_HALO - 1; u >= 0; --u) {  // rare: run longer than the halo
     const uint64_t ku = k[u];
     if (ku == kt) ++c;
     else if (mix_hi(ku, hsh) != ht) break;
@@ -38,14 +60,19 @@ __device__ static inline uint32_t count_back(const uint64_t *__restrict__ k, int
 __global__ __launch_bounds__(PAIR_THREADS) void pairs_count_kernel(const uint64_t *__restrict__ keys, int64_t nq,
                                                                    int ntiles, uint64_t ek, int hsh,
                                                                    uint64_t *__restrict__ blk) {
+  __shared__ uint64_t sk[PAIR_HALO + PAIR_TILE];
+  __shared__ uint32_t sh[PAIR_HALO + PAIR_TILE];
   __shared__ uint64_t sm[4];
   const int tile = blockIdx.x, band = blockIdx.y;
   const uint64_t *k = keys + (size_t)band * nq;
-  const int64_t t0 = (int64_t)tile * PAIR_TILE + (int64_t)threadIdx.x * PAIR_IPT;
+  const int64_t tile_start = (int64_t)tile * PAIR_TILE;
+  stage_tile(k, nq, tile_start, hsh, sk, sh);
+  __syncthreads();
+  const int tl0 = threadIdx.x * PAIR_IPT;
   uint64_t c = 0;
 #pragma unroll
   for (int i = 0; i < PAIR_IPT; ++i)
-    if (t0 + i < nq) c += count_back(k, t0 + i, ek, hsh);
+    if (tile_start + tl0 + i < nq) c += count_back(k, sk, sh, tile_start, tl0 + i, ek, hsh);
   uint64_t total;
   (void)block_excl_scan_u64_256(c, sm, &total);
   if (threadIdx.x == 0) blk[(size_t)band * ntiles + tile] = total;
@@ -56,16 +83,26 @@ __global__ __launch_bounds__(PAIR_THREADS) void pairs_fill_kernel(const uint64_t
                                                                   int ntiles, uint64_t ek, int hsh,
                                                                   const uint64_t *__restrict__ blk,
                                                                   uint64_t *__restrict__ out) {
+  __shared__ uint64_t sk[PAIR_HALO + PAIR_TILE];
+  __shared__ uint32_t sh[PAIR_HALO + PAIR_TILE];
+  __shared__ uint32_t si[PAIR_HALO + PAIR_TILE];
   __shared__ uint64_t sm[4];
   const int tile = blockIdx.x, band = blockIdx.y;
   const uint64_t *k = keys + (size_t)band * nq;
   const uint32_t *id = ids + (size_t)band * nq;
-  const int64_t t0 = (int64_t)tile * PAIR_TILE + (int64_t)threadIdx.x * PAIR_IPT;
+  const int64_t tile_start = (int64_t)tile * PAIR_TILE;
+  stage_tile(k, nq, tile_start, hsh, sk, sh);
+  for (int idx = threadIdx.x; idx < PAIR_HALO + PAIR_TILE; idx += PAIR_THREADS) {
+    const int64_t g = tile_start - PAIR_HALO + idx;
+    si[idx] = (g >= 0 && g < nq) ? id[g] : 0u;
+  }
+  __syncthreads();
+  const int tl0 = threadIdx.x * PAIR_IPT;
   uint32_t c[PAIR_IPT];
   uint64_t mine = 0;
 #pragma unroll
   for (int i = 0; i < PAIR_IPT; ++i) {
-    c[i] = (t0 + i < nq) ? count_back(k, t0 + i, ek, hsh) : 0;
+    c[i] = (tile_start + tl0 + i < nq) ? count_back(k, sk, sh, tile_start, tl0 + i, ek, hsh) : 0;
     mine += c[i];
   }
   uint64_t total;
@@ -73,15 +110,21 @@ __global__ __launch_bounds__(PAIR_THREADS) void pairs_fill_kernel(const uint64_t
 #pragma unroll
   for (int i = 0; i < PAIR_IPT; ++i) {
     if (c[i] == 0) continue;
-    const int64_t t = t0 + i;
-    const uint64_t kt = k[t];
-    const uint32_t it = id[t];
+    const int tl = tl0 + i;
+    const uint64_t kt = sk[PAIR_HALO + tl];
+    const uint32_t it = si[PAIR_HALO + tl];
     uint32_t left = c[i];
-    for (int64_t u = t - 1; left > 0; --u) {
+    for (int idx = PAIR_HALO + tl - 1; left > 0 && idx >= 0; --idx) {
+      if (sk[idx] == kt) {
+        const uint32_t iu = si[idx];
+        out[pos++] = ((uint64_t)(iu < it ? iu : it) << 32) | (iu < it ? it : iu);
+        --left;
+      }
+    }
+    for (int64_t u = tile_start - PAIR_HALO - 1; left > 0; --u) {  // rare: run longer than the halo
       if (k[u] == kt) {
         const uint32_t iu = id[u];
-        const uint32_t a = iu < it ? iu : it, bb = iu < it ? it : iu;
-        out[pos++] = ((uint64_t)a << 32) | bb;
+        out[pos++] = ((uint64_t)(iu < it ? iu : it) << 32) | (iu < it ? it : iu);
         --left;
       }
     }

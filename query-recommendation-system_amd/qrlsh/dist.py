@@ -192,7 +192,9 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
     rev_in = _exchange_var(_split_by_bounds(rev, ebounds), rev, group)
 
     # 7. local top-K
-    src, dst, val = be.topk(torch.cat([fwd, rev_in]), K, ib)
+    # order matters for the stable top-K sort: per src, reverse edges (dst < src, ascending by
+    # sender rank and pair order) come before forward edges (dst > src, ascending)
+    src, dst, val = be.topk(torch.cat([rev_in, fwd]), K, ib)
     stats["unique_pairs"] = int(pairs.numel())
     stats["kept_edges"] = int(src.numel())
     return HotPathResult(sig, norm2, pairs, milli, src, dst, val, K, b, stats)

@@ -277,7 +277,10 @@ def topk_edges(edges, K, id_bits):
     if n == 0:
         z = torch.empty((0,), dtype=torch.int32, device=dev)
         return z, z.clone(), z.clone()
-    se, _ = sort_u64(edges, None, 0, 2 * id_bits + 11)
+    # Sorting on (src, 1000-milli) alone is enough: the sort is stable and, per src, the edges
+    # arrive with dst ascending (pairs are sorted by (i, j); edge 2t is i->j, 2t+1 is j->i, so a
+    # src first meets its smaller neighbours, then its larger ones) -- 4 passes instead of 7.
+    se, _ = sort_u64(edges, None, id_bits, 2 * id_bits + 11)
     ws = _ws(lib.qrlsh_compact_workspace_bytes(n), dev)
     total = torch.zeros(1, dtype=torch.int64, device=dev)
     _lib.check(lib.qrlsh_topk_count(_ptr(se), n, K, id_bits, _ptr(ws), ws.numel(), _ptr(total), _stream()))
