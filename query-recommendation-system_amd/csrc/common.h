@@ -87,3 +87,30 @@ __device__ static inline uint64_t block_excl_scan_u64_256(uint64_t v, uint64_t *
   *total = tot;
   return base + inc - v;
 }
+
+// in-place exclusive scan of m uint64 (one workgroup); the grand total goes to *total_out
+static __global__ __launch_bounds__(1024) void scan_u64_kernel(uint64_t *__restrict__ a, int64_t m,
+                                                        uint64_t *__restrict__ total_out) {
+  __shared__ uint64_t wsum[16];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int64_t per = (m + 1023) / 1024;
+  const int64_t lo = min((int64_t)t * per, m), hi = min(lo + per, m);
+  uint64_t s = 0;
+  for (int64_t i = lo; i < hi; ++i) s += a[i];
+  const uint64_t inc = wave_incl_scan_u64(s);
+  if (lane == WAVE - 1) wsum[w] = inc;
+  __syncthreads();
+  uint64_t base = 0, tot = 0;
+  for (int i = 0; i < 16; ++i) {
+    if (i < w) base += wsum[i];
+    tot += wsum[i];
+  }
+  uint64_t run = base + inc - s;
+  for (int64_t i = lo; i < hi; ++i) {
+    const uint64_t v = a[i];
+    a[i] = run;
+    run += v;
+  }
+  if (t == 0) *total_out = tot;
+}
+

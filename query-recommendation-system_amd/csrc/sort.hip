@@ -23,11 +23,19 @@ template <bool MIX> __device__ static inline uint32_t digit_of(uint64_t key, int
   return (uint32_t)(x >> shift) & (RADIX - 1);
 }
 
+// Partition digit of the fast bucket path: records holding the "empty" key (all -1 band,
+// never a candidate: lsh.py:47) are dealt round the parts by their index instead of all
+// landing in one part, so a data set with many empty answer sets cannot overflow a part.
+template <bool SPREAD> __device__ static inline uint32_t part_digit(uint64_t key, int64_t idx, int shift, uint64_t ek) {
+  if (SPREAD && key == ek) return (uint32_t)(qr_mix64((uint64_t)idx) >> 56) & (RADIX - 1);
+  return digit_of<true>(key, shift);
+}
+
 // ghist layout: [batch][digit][tile]
-template <bool MIX>
+template <bool MIX, bool SPREAD = false>
 __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const uint64_t *__restrict__ keys, int64_t n,
                                                                  int ntiles, int shift,
-                                                                 uint32_t *__restrict__ ghist) {
+                                                                 uint32_t *__restrict__ ghist, uint64_t ek = 0) {
   __shared__ uint32_t h[RADIX];
   const int tile = blockIdx.x, batch = blockIdx.y;
   h[threadIdx.x] = 0;
@@ -37,7 +45,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const uint64_t 
 #pragma unroll
   for (int i = 0; i < SORT_IPT; ++i) {
     const int64_t idx = base + (int64_t)i * SORT_THREADS + threadIdx.x;
-    if (idx < n) atomicAdd(&h[digit_of<MIX>(k[idx], shift)], 1u);
+    if (idx < n) atomicAdd(&h[SPREAD ? part_digit<SPREAD>(k[idx], idx, shift, ek) : digit_of<MIX>(k[idx], shift)], 1u);
   }
   __syncthreads();
   ghist[((size_t)batch * RADIX + threadIdx.x) * ntiles + tile] = h[threadIdx.x];
@@ -78,14 +86,15 @@ __global__ __launch_bounds__(256) void sort_rowscan_kernel(uint32_t *__restrict_
   if (t == 0) rtot[(size_t)batch * RADIX + d] = carry;
 }
 
-template <bool MIX, bool HAS_VAL, bool IOTA>
+template <bool MIX, bool HAS_VAL, bool IOTA, bool SPREAD = false>
 __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const uint64_t *__restrict__ keys_in,
                                                                     const uint32_t *__restrict__ vals_in,
                                                                     uint64_t *__restrict__ keys_out,
                                                                     uint32_t *__restrict__ vals_out, int64_t n,
                                                                     int ntiles, int shift,
                                                                     const uint32_t *__restrict__ goff,
-                                                                    const uint32_t *__restrict__ rtot) {
+                                                                    const uint32_t *__restrict__ rtot,
+                                                                    uint64_t ek = 0) {
   __shared__ uint32_t cnt[SORT_THREADS / WAVE][RADIX];
   __shared__ uint32_t dsum[SORT_THREADS / WAVE];
   const int tile = blockIdx.x, batch = blockIdx.y;
@@ -112,7 +121,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const uint64
   for (int k = 0; k < SORT_IPT; ++k) {
     const int64_t idx = wbase + (int64_t)k * WAVE + lane;
     const bool valid = idx < n;
-    const uint32_t d = digit_of<MIX>(key[k], shift);
+    const uint32_t d = SPREAD ? part_digit<SPREAD>(key[k], idx, shift, ek) : digit_of<MIX>(key[k], shift);
     uint64_t m = __ballot(valid);
 #pragma unroll
     for (int bit = 0; bit < 8; ++bit) {
@@ -227,4 +236,193 @@ QRLSH_EXPORT int qrlsh_sort_u64(uint64_t *keys_a, uint64_t *keys_b, uint32_t *va
   if (flags & QRLSH_SORT_MIX)
     return sort_passes<true>(keys_a, keys_b, vals_a, vals_b, n, nbatch, bit_lo, bit_hi, iota, ghist, st);
   return sort_passes<false>(keys_a, keys_b, vals_a, vals_b, n, nbatch, bit_lo, bit_hi, iota, ghist, st);
+}
+
+// ==========================================================================================
+// Fast bucket path (a2/a3): ONE partition pass + an LDS finish, instead of a full sort.
+//
+//   partition : the first radix pass above on the top 8 bits of mix64(key) (with IOTA ids)
+//               -> per band 256 parts of ~nq/256 records, contiguous in HBM;
+//   finish    : one 1024-thread workgroup per (part, band) stages the part in LDS, links
+//               equal keys through an LDS hash table (atomicExch chains) and, per record,
+//               pairs it with every record of the part that has the same FULL key and a
+//               smaller query id -- exactly the (i < j) pairs of that bucket (lsh.py:47-49).
+//
+// Count-then-fill like the general path; a part larger than FIN_CAP records (heavily skewed
+// data) raises the overflow word and the host falls back to the general sort path.
+// ==========================================================================================
+constexpr int FIN_THREADS = 1024;
+constexpr int FIN_CAP = 6144;   // records per part that fit the LDS image
+constexpr int FIN_HT = 8192;    // hash-table heads
+constexpr int FIN_IPT = FIN_CAP / FIN_THREADS;
+constexpr uint32_t FIN_NIL = 0xFFFFu;
+
+template <bool FILL>
+__global__ __launch_bounds__(FIN_THREADS) void bucket_finish_kernel(const uint64_t *__restrict__ keys,
+                                                                    const uint32_t *__restrict__ ids, int64_t nq,
+                                                                    const uint32_t *__restrict__ rtot, uint64_t ek,
+                                                                    uint64_t *__restrict__ blk,
+                                                                    uint32_t *__restrict__ overflow,
+                                                                    uint64_t *__restrict__ out) {
+  __shared__ uint64_t sk[FIN_CAP];
+  __shared__ uint32_t si[FIN_CAP];
+  __shared__ uint32_t head[FIN_HT];
+  __shared__ uint16_t nxt[FIN_CAP];
+  __shared__ uint64_t wsum[FIN_THREADS / WAVE];
+  __shared__ uint32_t dsum[4];
+  __shared__ uint32_t s_start, s_size;
+  const int part = blockIdx.x, band = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid >> 6;
+
+  // part offset = exclusive prefix of the band's 256 part sizes
+  if (tid < RADIX) {
+    const uint32_t tot = rtot[(size_t)band * RADIX + tid];
+    uint32_t inc = tot;
+#pragma unroll
+    for (int k = 1; k < WAVE; k <<= 1) {
+      const uint32_t o = __shfl_up(inc, k, WAVE);
+      if (lane >= k) inc += o;
+    }
+    if (lane == WAVE - 1) dsum[w] = inc;
+    head[tid] = inc - tot;  // temporaries: within-wave exclusive prefix and the part size
+    si[tid] = tot;
+  }
+  __syncthreads();
+  if (tid == part) {
+    uint32_t base = head[tid];
+    for (int k = 0; k < (tid >> 6); ++k) base += dsum[k];
+    s_start = base;
+    s_size = si[tid];
+  }
+  __syncthreads();
+  const uint32_t start = s_start, m = s_size;
+  if (m > (uint32_t)FIN_CAP) {  // uniform over the workgroup
+    if (tid == 0) {
+      atomicOr(overflow, 1u);
+      if (!FILL) blk[(size_t)band * RADIX + part] = 0;
+    }
+    return;
+  }
+  for (int i = tid; i < FIN_HT; i += FIN_THREADS) head[i] = 0xFFFFFFFFu;
+  const uint64_t *k = keys + (size_t)band * nq + start;
+  const uint32_t *id = ids + (size_t)band * nq + start;
+  for (uint32_t i = tid; i < m; i += FIN_THREADS) {
+    sk[i] = k[i];
+    si[i] = id[i];
+  }
+  __syncthreads();
+  for (uint32_t i = tid; i < m; i += FIN_THREADS) {
+    const uint64_t key = sk[i];
+    if (key != ek) {
+      const uint32_t slot = (uint32_t)(qr_mix64(key) >> 24) & (FIN_HT - 1);
+      nxt[i] = (uint16_t)atomicExch(&head[slot], i);
+    }
+  }
+  __syncthreads();
+
+  uint32_t c[FIN_IPT];
+  uint64_t mine = 0;
+#pragma unroll
+  for (int j = 0; j < FIN_IPT; ++j) {
+    const uint32_t i = tid + j * FIN_THREADS;
+    uint32_t cnt = 0;
+    if (i < m) {
+      const uint64_t key = sk[i];
+      if (key != ek) {
+        const uint32_t myid = si[i];
+        const uint32_t slot = (uint32_t)(qr_mix64(key) >> 24) & (FIN_HT - 1);
+        for (uint32_t u = head[slot] & 0xFFFFu; u != FIN_NIL; u = nxt[u])
+          if (sk[u] == key && si[u] < myid) ++cnt;
+      }
+    }
+    c[j] = cnt;
+    mine += cnt;
+  }
+  // block exclusive scan over 1024 threads
+  const uint64_t inc = wave_incl_scan_u64(mine);
+  if (lane == WAVE - 1) wsum[w] = inc;
+  __syncthreads();
+  uint64_t base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < FIN_THREADS / WAVE; ++i) {
+    const uint64_t x = wsum[i];
+    if (i < w) base += x;
+    tot += x;
+  }
+  if (!FILL) {
+    if (tid == 0) blk[(size_t)band * RADIX + part] = tot;
+    return;
+  }
+  uint64_t pos = blk[(size_t)band * RADIX + part] + base + inc - mine;
+#pragma unroll
+  for (int j = 0; j < FIN_IPT; ++j) {
+    if (c[j] == 0) continue;
+    const uint32_t i = tid + j * FIN_THREADS;
+    const uint64_t key = sk[i];
+    const uint32_t myid = si[i];
+    const uint32_t slot = (uint32_t)(qr_mix64(key) >> 24) & (FIN_HT - 1);
+    for (uint32_t u = head[slot] & 0xFFFFu; u != FIN_NIL; u = nxt[u])
+      if (sk[u] == key && si[u] < myid) out[pos++] = ((uint64_t)si[u] << 32) | myid;
+  }
+}
+
+// workspace: [ghist+rtot of one sort pass][blk: b*256 u64][total u64][overflow u32 (+pad)]
+static size_t bucket_ws_sort_bytes(int64_t nq, int32_t b) { return (qrlsh_sort_workspace_bytes(nq, b) + 15) & ~(size_t)15; }
+
+QRLSH_EXPORT size_t qrlsh_bucket_workspace_bytes(int64_t nq, int32_t b) {
+  if (nq <= 0 || b <= 0) return 64;
+  return bucket_ws_sort_bytes(nq, b) + (size_t)b * RADIX * sizeof(uint64_t) + 16;
+}
+
+QRLSH_EXPORT int qrlsh_bucket_pairs_count(const uint64_t *keys, uint64_t *part_keys, uint32_t *part_ids, int64_t nq,
+                                          int32_t b, int32_t r, void *workspace, size_t workspace_bytes,
+                                          uint64_t *total_overflow_out, void *stream) {
+  QR_CHECK_ARG(nq >= 0 && b > 0 && b <= 65535 && r > 0 && r <= 4, "qrlsh_bucket_pairs_count: bad sizes nq=%lld b=%d r=%d",
+               (long long)nq, b, r);
+  QR_CHECK_ARG(nq < (1ll << 32), "qrlsh_bucket_pairs_count: nq too large");
+  QR_CHECK_ARG(total_overflow_out && workspace, "qrlsh_bucket_pairs_count: null pointer");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(total_overflow_out, 0, 2 * sizeof(uint64_t), st) != hipSuccess) {
+    qrlsh_set_error("qrlsh_bucket_pairs_count: hipMemsetAsync failed");
+    return QRLSH_EHIP;
+  }
+  if (nq == 0) return QRLSH_OK;
+  QR_CHECK_ARG(keys && part_keys && part_ids, "qrlsh_bucket_pairs_count: null pointer");
+  if (workspace_bytes < qrlsh_bucket_workspace_bytes(nq, b)) {
+    qrlsh_set_error("qrlsh_bucket_pairs_count: workspace %zu < %zu bytes", workspace_bytes,
+                    qrlsh_bucket_workspace_bytes(nq, b));
+    return QRLSH_EWORKSPACE;
+  }
+  const int ntiles = (int)ceil_div64(nq, SORT_TILE);
+  uint32_t *ghist = static_cast<uint32_t *>(workspace);
+  uint32_t *rtot = ghist + (size_t)b * RADIX * ntiles;
+  uint64_t *blk = reinterpret_cast<uint64_t *>(static_cast<char *>(workspace) + bucket_ws_sort_bytes(nq, b));
+  const dim3 grid(ntiles, b), block(SORT_THREADS);
+  const int shift = 56;
+  const uint64_t ek = qr_empty_key(r);
+  QR_LAUNCH("sort_hist", (sort_hist_kernel<true, true>), grid, block, 0, st, keys, nq, ntiles, shift, ghist, ek);
+  QR_LAUNCH("sort_rowscan", sort_rowscan_kernel, dim3(RADIX, b), dim3(256), 0, st, ghist, ntiles, rtot);
+  QR_LAUNCH("sort_scatter_kv", (sort_scatter_kernel<true, true, true, true>), grid, block, 0, st, keys,
+            (const uint32_t *)nullptr, part_keys, part_ids, nq, ntiles, shift, ghist, rtot, ek);
+  QR_LAUNCH("bucket_count", (bucket_finish_kernel<false>), dim3(RADIX, b), dim3(FIN_THREADS), 0, st, part_keys, part_ids,
+            nq, rtot, qr_empty_key(r), blk, reinterpret_cast<uint32_t *>(total_overflow_out + 1), (uint64_t *)nullptr);
+  QR_LAUNCH("scan_blocks", scan_u64_kernel, dim3(1), dim3(1024), 0, st, blk, (int64_t)b * RADIX, total_overflow_out);
+  QR_LAUNCH_CHECK("qrlsh_bucket_pairs_count");
+  return QRLSH_OK;
+}
+
+QRLSH_EXPORT int qrlsh_bucket_pairs_fill(const uint64_t *part_keys, const uint32_t *part_ids, int64_t nq, int32_t b,
+                                         int32_t r, void *workspace, uint64_t *pairs_out, void *stream) {
+  QR_CHECK_ARG(nq >= 0 && b > 0 && r > 0 && r <= 4, "qrlsh_bucket_pairs_fill: bad sizes");
+  if (nq == 0) return QRLSH_OK;
+  QR_CHECK_ARG(part_keys && part_ids && workspace && pairs_out, "qrlsh_bucket_pairs_fill: null pointer");
+  const int ntiles = (int)ceil_div64(nq, SORT_TILE);
+  uint32_t *ghist = static_cast<uint32_t *>(workspace);
+  uint32_t *rtot = ghist + (size_t)b * RADIX * ntiles;
+  uint64_t *blk = reinterpret_cast<uint64_t *>(static_cast<char *>(workspace) + bucket_ws_sort_bytes(nq, b));
+  uint32_t *ovf = reinterpret_cast<uint32_t *>(blk + (size_t)b * RADIX);  // scratch word (result ignored here)
+  QR_LAUNCH("bucket_fill", (bucket_finish_kernel<true>), dim3(RADIX, b), dim3(FIN_THREADS), 0,
+            static_cast<hipStream_t>(stream), part_keys, part_ids, nq, rtot, qr_empty_key(r), blk, ovf, pairs_out);
+  QR_LAUNCH_CHECK("qrlsh_bucket_pairs_fill");
+  return QRLSH_OK;
 }

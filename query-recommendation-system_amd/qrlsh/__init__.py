@@ -14,6 +14,8 @@ from .ops import (  # noqa: F401
     sort_u64,
     bucket_sort,
     emit_pairs,
+    emit_pairs_fast,
+    emit_pairs_any,
     unique_sorted,
     candidate_pairs,
     score_pairs,

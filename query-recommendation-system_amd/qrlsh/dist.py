@@ -37,8 +37,7 @@ class HipBackend:
         return ops.minhash(offsets, rows, table, b=b, want_norm=True)
 
     def emit_pairs(self, keys, r):
-        sk, sid = ops.bucket_sort(keys)
-        return ops.emit_pairs(sk, sid, r)
+        return ops.emit_pairs_any(keys, r)
 
     def sort_unique(self, words, bit_ranges):
         for lo, hi in bit_ranges:

@@ -234,12 +234,45 @@ def sort_pairs(pairs, nq):
     return p
 
 
+def emit_pairs_fast(keys, r):
+    """emit_pairs for unsorted band-major keys through the partition + LDS-finish path.
+    Returns the pairs tensor, or None when a part overflowed the LDS image (skewed data)."""
+    lib = _lib.load()
+    _need(keys, torch.int64, "keys", 2)
+    b, nq = keys.shape
+    dev = keys.device
+    pk = torch.empty_like(keys)
+    pid = torch.empty((b, nq), dtype=torch.int32, device=dev)
+    ws = _ws(lib.qrlsh_bucket_workspace_bytes(nq, b), dev)
+    tot = torch.zeros(2, dtype=torch.int64, device=dev)
+    _lib.check(lib.qrlsh_bucket_pairs_count(_ptr(keys), _ptr(pk), _ptr(pid), nq, b, r, _ptr(ws), ws.numel(), _ptr(tot),
+                                            _stream()))
+    n, overflow = tot.tolist()
+    if overflow:
+        return None
+    pairs = torch.empty((n,), dtype=torch.int64, device=dev)
+    if n:
+        _lib.check(lib.qrlsh_bucket_pairs_fill(_ptr(pk), _ptr(pid), nq, b, r, _ptr(ws), _ptr(pairs), _stream()))
+    return pairs
+
+
+def emit_pairs_any(keys, r, stats=None):
+    """All (i<j) pairs of every non-empty bucket, every band, from unsorted band-major keys
+    [b,nq] (keys may be consumed): fast path, or the general sort path when it overflows."""
+    emitted = emit_pairs_fast(keys, r)
+    if stats is not None:
+        stats["bucket_path"] = "partition+lds" if emitted is not None else "general-sort"
+    if emitted is None:
+        sk, sid = bucket_sort(keys)
+        emitted = emit_pairs(sk, sid, r)
+    return emitted
+
+
 def candidate_pairs(keys, r, stats=None):
     """get_candidates (lsh.py:40-55) on band-major keys [b,nq] (consumed): sorted unique
     int64 array of i<<32|j, i<j."""
     b, nq = keys.shape
-    sk, sid = bucket_sort(keys)
-    emitted = emit_pairs(sk, sid, r)
+    emitted = emit_pairs_any(keys, r, stats)
     if stats is not None:
         stats["emitted_pairs"] = int(emitted.numel())
     if emitted.numel() == 0:

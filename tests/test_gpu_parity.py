@@ -351,3 +351,34 @@ def test_sharded_driver_on_gpu_equals_single_gpu(tmp_path, world, mode, backend)
     assert np.array_equal(np.concatenate([o["dst"] for o in outs]), res.dst.cpu().numpy())
     assert np.array_equal(np.concatenate([o["val"] for o in outs]), res.val.cpu().numpy())
     assert sum(int(o["emitted"]) for o in outs) == res.stats["emitted_pairs"]
+
+
+# ---------------------------------------------------------------------------- fast bucket path
+def test_fast_bucket_path_equals_general_path():
+    rng = np.random.default_rng(11)
+    for (nq, b, nkeys) in [(1, 2, 5), (50, 3, 7), (5000, 4, 900), (70000, 8, 20000), (300000, 2, 40)]:
+        k = rng.integers(0, nkeys, size=(b, nq), dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        k[0, : nq // 3] = np.uint64(0xFFFFFFFFFFFFFFFF)         # "empty" keys must never pair (lsh.py:47)
+        if nkeys == 40:
+            with_cap = ops.emit_pairs_fast(dev(k.view(np.int64)), 4)
+            assert with_cap is None                              # 300000/40 per key > LDS image -> overflow
+            continue
+        fast = ops.emit_pairs_fast(dev(k.view(np.int64)), 4)
+        sk, sid = ops.bucket_sort(dev(k.view(np.int64)))
+        gen = ops.emit_pairs(sk, sid, 4)
+        assert fast is not None and fast.numel() == gen.numel()
+        assert np.array_equal(np.sort(u64(fast)), np.sort(u64(gen)))
+
+
+def test_overflowing_part_falls_back_to_general_path():
+    sig = np.random.default_rng(5).integers(0, 30000, size=(9000, 4)).astype(np.int32)
+    sig[1000:8000] = sig[0]                                      # 7001 identical -> one part > FIN_CAP
+    keys = ops.band_keys(dev(sig), 1)
+    st = {}
+    pairs = ops.candidate_pairs(keys, 4, st)
+    assert st["bucket_path"] == "general-sort"
+    ref = O.candidates(O.band_keys(sig, 1), 4)
+    assert np.array_equal(u64(pairs), ref) and len(ref) >= 7001 * 7000 // 2
+    st2 = {}
+    ops.candidate_pairs(ops.band_keys(dev(sig[:900]), 1), 4, st2)
+    assert st2["bucket_path"] == "partition+lds"

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Per-kernel timing on the standard workload (config 2 by default) using the library's
+HIP-event profiler.  Development tool: python tools/kbench.py [--nq N] [--reps R] [--stage all|minhash|bucket|score]"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "query-recommendation-system_amd")):
+    sys.path.insert(0, p)
+import torch  # noqa: E402
+import qrlsh  # noqa: E402
+from qrlsh import ops, pipeline, _lib  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--nq", type=int, default=1_000_000)
+    ap.add_argument("--perm", type=int, default=128)
+    ap.add_argument("--bands", type=int, default=32)
+    ap.add_argument("--drows", type=int, default=32768)
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--stage", default="all")
+    a = ap.parse_args()
+    dev = "cuda"
+    off, rows = qrlsh.synth_csr(a.nq, a.drows, seed=0, device=dev)
+    table = ops.perm_table(ops.legacy_permutations(a.perm, a.drows, seed=42), dev)
+    K = pipeline.max_candidates(a.nq)
+    r = a.perm // a.bands
+
+    def run():
+        if a.stage == "all":
+            pipeline.query_similarities(off, rows, table, a.bands, K)
+        elif a.stage == "minhash":
+            ops.minhash(off, rows, table, b=a.bands)
+        elif a.stage == "bucket":
+            _, _, keys = ops.minhash(off, rows, table, b=a.bands)
+            ops.emit_pairs_any(keys, r)
+        elif a.stage == "score":
+            pipeline.query_similarities(off, rows, table, a.bands, K)
+
+    run()
+    torch.cuda.synchronize()
+    _lib.prof_enable(True)
+    for _ in range(a.reps):
+        run()
+    torch.cuda.synchronize()
+    rep = _lib.prof_report()
+    _lib.prof_enable(False)
+    tot = 0.0
+    for k, (c, ms) in sorted(rep.items(), key=lambda kv: -kv[1][1]):
+        print("%-18s launches/run %5.1f  ms/run %8.4f  avg %8.4f" % (k, c / a.reps, ms / a.reps, ms / c))
+        tot += ms / a.reps
+    print("sum of kernels: %.4f ms/run" % tot)
+
+
+if __name__ == "__main__":
+    main()
