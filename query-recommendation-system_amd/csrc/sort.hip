@@ -18,6 +18,15 @@ constexpr int SORT_IPT = 16;                          // items per thread
 constexpr int SORT_TILE = SORT_THREADS * SORT_IPT;    // 4096 keys per workgroup
 constexpr int RADIX = 256;
 
+// Workgroups b and b+8 share an XCD (round-robin dispatch; speed only, never correctness).
+// Remap so each XCD works on a contiguous range of tiles: the runs that neighbouring tiles
+// write for one digit are adjacent in memory, and their shared 64-B sectors then merge in
+// ONE L2 instead of being written back partially by two.
+__device__ static inline int xcd_tile(int bid, int ntiles) {
+  const int q = ntiles >> 3, r = ntiles & 7, x = bid & 7, y = bid >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+}
+
 template <bool MIX> __device__ static inline uint32_t digit_of(uint64_t key, int shift) {
   const uint64_t x = MIX ? qr_mix64(key) : key;
   return (uint32_t)(x >> shift) & (RADIX - 1);
@@ -97,7 +106,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const uint64
                                                                     uint64_t ek = 0) {
   __shared__ uint32_t cnt[SORT_THREADS / WAVE][RADIX];
   __shared__ uint32_t dsum[SORT_THREADS / WAVE];
-  const int tile = blockIdx.x, batch = blockIdx.y;
+  const int tile = xcd_tile(blockIdx.x, ntiles), batch = blockIdx.y;
   const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x >> 6;
 #pragma unroll
   for (int i = 0; i < SORT_THREADS / WAVE; ++i) cnt[i][threadIdx.x] = 0;
@@ -253,10 +262,24 @@ QRLSH_EXPORT int qrlsh_sort_u64(uint64_t *keys_a, uint64_t *keys_b, uint32_t *va
 // ==========================================================================================
 constexpr int FIN_THREADS = 1024;
 constexpr int FIN_CAP = 6144;   // records per part that fit the LDS image
-constexpr int FIN_HT = 8192;    // hash-table heads
+constexpr int FIN_HT = 4096;    // hash-table heads
 constexpr int FIN_IPT = FIN_CAP / FIN_THREADS;
 constexpr uint32_t FIN_NIL = 0xFFFFu;
 
+// cheap 32-bit slot hash for the LDS table (quality only affects chain length, never results)
+__device__ static inline uint32_t fin_slot(uint64_t key) {
+  uint32_t h = (uint32_t)key * 0x9E3779B1u;
+  h ^= h >> 15;
+  h += (uint32_t)(key >> 32) * 0x85EBCA77u;
+  h ^= h >> 13;
+  h *= 0xC2B2AE3Du;
+  return h >> (32 - 12);  // FIN_HT = 4096
+}
+
+// The partition pass is stable and ids enter in ascending order (IOTA), so inside a part
+// "smaller query id" == "earlier position": the finish never needs the ids to decide, only to
+// write a pair (fill reads them from global memory, L2-hot).  LDS image: keys 48 KB + heads
+// 16 KB + links 12 KB = 76 KB -> two workgroups per CU.
 template <bool FILL>
 __global__ __launch_bounds__(FIN_THREADS) void bucket_finish_kernel(const uint64_t *__restrict__ keys,
                                                                     const uint32_t *__restrict__ ids, int64_t nq,
@@ -265,7 +288,6 @@ __global__ __launch_bounds__(FIN_THREADS) void bucket_finish_kernel(const uint64
                                                                     uint32_t *__restrict__ overflow,
                                                                     uint64_t *__restrict__ out) {
   __shared__ uint64_t sk[FIN_CAP];
-  __shared__ uint32_t si[FIN_CAP];
   __shared__ uint32_t head[FIN_HT];
   __shared__ uint16_t nxt[FIN_CAP];
   __shared__ uint64_t wsum[FIN_THREADS / WAVE];
@@ -284,15 +306,15 @@ __global__ __launch_bounds__(FIN_THREADS) void bucket_finish_kernel(const uint64
       if (lane >= k) inc += o;
     }
     if (lane == WAVE - 1) dsum[w] = inc;
-    head[tid] = inc - tot;  // temporaries: within-wave exclusive prefix and the part size
-    si[tid] = tot;
+    head[tid] = inc - tot;        // temporaries: within-wave exclusive prefix ...
+    head[RADIX + tid] = tot;      // ... and the part size
   }
   __syncthreads();
   if (tid == part) {
     uint32_t base = head[tid];
     for (int k = 0; k < (tid >> 6); ++k) base += dsum[k];
     s_start = base;
-    s_size = si[tid];
+    s_size = head[RADIX + tid];
   }
   __syncthreads();
   const uint32_t start = s_start, m = s_size;
@@ -305,18 +327,24 @@ __global__ __launch_bounds__(FIN_THREADS) void bucket_finish_kernel(const uint64
   }
   for (int i = tid; i < FIN_HT; i += FIN_THREADS) head[i] = 0xFFFFFFFFu;
   const uint64_t *k = keys + (size_t)band * nq + start;
-  const uint32_t *id = ids + (size_t)band * nq + start;
-  for (uint32_t i = tid; i < m; i += FIN_THREADS) {
-    sk[i] = k[i];
-    si[i] = id[i];
+  uint64_t kreg[FIN_IPT];
+#pragma unroll
+  for (int j = 0; j < FIN_IPT; ++j) {
+    const uint32_t i = tid + j * FIN_THREADS;
+    kreg[j] = i < m ? k[i] : ek;
+  }
+#pragma unroll
+  for (int j = 0; j < FIN_IPT; ++j) {
+    const uint32_t i = tid + j * FIN_THREADS;
+    if (i < m) sk[i] = kreg[j];
   }
   __syncthreads();
-  for (uint32_t i = tid; i < m; i += FIN_THREADS) {
-    const uint64_t key = sk[i];
-    if (key != ek) {
-      const uint32_t slot = (uint32_t)(qr_mix64(key) >> 24) & (FIN_HT - 1);
-      nxt[i] = (uint16_t)atomicExch(&head[slot], i);
-    }
+  uint32_t slot[FIN_IPT];
+#pragma unroll
+  for (int j = 0; j < FIN_IPT; ++j) {
+    const uint32_t i = tid + j * FIN_THREADS;
+    slot[j] = fin_slot(kreg[j]);
+    if (kreg[j] != ek) nxt[i] = (uint16_t)atomicExch(&head[slot[j]], i);
   }
   __syncthreads();
 
@@ -326,14 +354,9 @@ __global__ __launch_bounds__(FIN_THREADS) void bucket_finish_kernel(const uint64
   for (int j = 0; j < FIN_IPT; ++j) {
     const uint32_t i = tid + j * FIN_THREADS;
     uint32_t cnt = 0;
-    if (i < m) {
-      const uint64_t key = sk[i];
-      if (key != ek) {
-        const uint32_t myid = si[i];
-        const uint32_t slot = (uint32_t)(qr_mix64(key) >> 24) & (FIN_HT - 1);
-        for (uint32_t u = head[slot] & 0xFFFFu; u != FIN_NIL; u = nxt[u])
-          if (sk[u] == key && si[u] < myid) ++cnt;
-      }
+    if (kreg[j] != ek) {
+      for (uint32_t u = head[slot[j]] & 0xFFFFu; u != FIN_NIL; u = nxt[u])
+        if (u < i && sk[u] == kreg[j]) ++cnt;
     }
     c[j] = cnt;
     mine += cnt;
@@ -353,16 +376,15 @@ __global__ __launch_bounds__(FIN_THREADS) void bucket_finish_kernel(const uint64
     if (tid == 0) blk[(size_t)band * RADIX + part] = tot;
     return;
   }
+  const uint32_t *id = ids + (size_t)band * nq + start;
   uint64_t pos = blk[(size_t)band * RADIX + part] + base + inc - mine;
 #pragma unroll
   for (int j = 0; j < FIN_IPT; ++j) {
     if (c[j] == 0) continue;
     const uint32_t i = tid + j * FIN_THREADS;
-    const uint64_t key = sk[i];
-    const uint32_t myid = si[i];
-    const uint32_t slot = (uint32_t)(qr_mix64(key) >> 24) & (FIN_HT - 1);
-    for (uint32_t u = head[slot] & 0xFFFFu; u != FIN_NIL; u = nxt[u])
-      if (sk[u] == key && si[u] < myid) out[pos++] = ((uint64_t)si[u] << 32) | myid;
+    const uint32_t myid = id[i];
+    for (uint32_t u = head[slot[j]] & 0xFFFFu; u != FIN_NIL; u = nxt[u])
+      if (u < i && sk[u] == kreg[j]) out[pos++] = ((uint64_t)id[u] << 32) | myid;
   }
 }
 
