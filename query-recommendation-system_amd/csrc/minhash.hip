@@ -131,6 +131,133 @@ __global__ __launch_bounds__(256) void minhash_kernel(const int64_t *__restrict_
   }
 }
 
+// ---- v2: one LPR-lane GROUP per query, G = 64/LPR queries in flight per wave ----------------
+// The v1 kernel above walks one query per wave and pays three dependent memory latencies
+// (offsets -> row ids -> table rows) per query with nothing else in flight.  Here a wave owns
+// 16 consecutive queries: their 17 offsets come from ONE coalesced load, each group gathers
+// all rows of ITS query with independent 16-B loads (no cross-group reduction: every lane ends
+// up with the final minimum of its 16-B column chunk), and the row ids of the next batch of G
+// queries are prefetched while the current batch's gathers are in flight.
+constexpr int MH_QPW = 16;  // queries per wave (4 waves -> 64 per workgroup)
+
+template <typename TabT, int LPR>
+__global__ __launch_bounds__(256) void minhash_group_kernel(const int64_t *__restrict__ offsets,
+                                                            const int32_t *__restrict__ rows, int64_t nq,
+                                                            const TabT *__restrict__ tab, int P, int P_stride,
+                                                            int32_t *__restrict__ sig, int64_t *__restrict__ norm2,
+                                                            uint64_t *__restrict__ keys, int b, int r) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint16_t *s16 = reinterpret_cast<uint16_t *>(smem_raw);  // [64][ldk] low-16 signature image
+  using VecT = typename TabVec<TabT>::type;
+  constexpr int VEC = TabVec<TabT>::N;
+  constexpr int G = WAVE / LPR;
+  constexpr int QPB = 4 * MH_QPW;
+  const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
+  const int g = lane / LPR, lig = lane % LPR;
+  const int64_t q0 = (int64_t)blockIdx.x * QPB;
+  const int64_t qw0 = q0 + wave * MH_QPW;
+  const int ldk = P + 2;
+  const int col = lig * VEC;
+  const bool colok = col < P_stride;
+  const bool vec_store = (P % 4) == 0;
+
+  // 17 offsets of this wave's 16 queries in one load
+  int64_t offs = 0;
+  {
+    const int64_t qi = qw0 + lane;
+    if (lane <= MH_QPW) offs = offsets[qi < nq ? qi : nq];
+  }
+  auto batch_lo = [&](int batch, int &n) -> int64_t {
+    const int ql = batch * G + g;
+    const int64_t lo = __shfl(offs, ql, WAVE), hi = __shfl(offs, ql + 1, WAVE);
+    n = (qw0 + ql < nq) ? (int)(hi - lo) : 0;
+    return lo;
+  };
+  int n_cur;
+  int64_t lo_cur = batch_lo(0, n_cur);
+  int my_cur = (lig < n_cur) ? rows[lo_cur + lig] : 0;
+
+#pragma unroll 1
+  for (int batch = 0; batch < MH_QPW / G; ++batch) {
+    const int ql = wave * MH_QPW + batch * G + g;  // query index inside the workgroup
+    const int64_t q = q0 + ql;
+    // prefetch the next batch's first LPR row ids
+    int n_nxt = 0, my_nxt = 0;
+    int64_t lo_nxt = 0;
+    if (batch + 1 < MH_QPW / G) {
+      lo_nxt = batch_lo(batch + 1, n_nxt);
+      if (lig < n_nxt) my_nxt = rows[lo_nxt + lig];
+    }
+    VecT acc = TabVec<TabT>::init();
+    int my = my_cur;
+    for (int base = 0; __any(base < n_cur); base += LPR) {
+      if (base > 0) my = (base + lig < n_cur) ? rows[lo_cur + base + lig] : 0;
+      const int cnt = min(LPR, n_cur - base);
+#pragma unroll
+      for (int i = 0; i < LPR; ++i) {
+        const int d = __shfl(my, g * LPR + i, WAVE);
+        if (i < cnt && colok) {
+          const VecT v = *reinterpret_cast<const VecT *>(tab + (size_t)d * P_stride + col);
+          acc = __builtin_elementwise_min(acc, v);
+        }
+      }
+    }
+    if (q < nq) {
+      int64_t nrm = 0;
+      if (colok) {
+        int32_t out[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) out[e] = (n_cur > 0) ? (int32_t)acc[e] : -1;
+        int32_t *dst = sig + (size_t)q * P + col;
+        if (vec_store && col + VEC <= P) {
+#pragma unroll
+          for (int e = 0; e < VEC; e += 4)
+            *reinterpret_cast<i32x4 *>(dst + e) = (i32x4){out[e], out[e + 1], out[e + 2], out[e + 3]};
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) nrm += (int64_t)out[e] * out[e];
+          if (keys) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) s16[ql * ldk + col + e] = (uint16_t)out[e];
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e)
+            if (col + e < P) {
+              dst[e] = out[e];
+              nrm += (int64_t)out[e] * out[e];
+              if (keys) s16[ql * ldk + col + e] = (uint16_t)out[e];
+            }
+        }
+      }
+      if (norm2) {
+#pragma unroll
+        for (int m = 1; m < LPR; m <<= 1) nrm += __shfl_xor(nrm, m, WAVE);
+        if (lig == 0) norm2[q] = nrm;
+      }
+    } else if (norm2) {
+#pragma unroll
+      for (int m = 1; m < LPR; m <<= 1) (void)__shfl_xor((int64_t)0, m, WAVE);
+    }
+    n_cur = n_nxt;
+    lo_cur = lo_nxt;
+    my_cur = my_nxt;
+  }
+
+  if (keys) {
+    __syncthreads();
+    const int nql = (int)min((int64_t)QPB, nq - q0);
+    for (int idx = threadIdx.x; idx < QPB * b; idx += blockDim.x) {
+      const int ql = idx % QPB, band = idx / QPB;
+      if (ql < nql) {
+        const uint16_t *sp = s16 + ql * ldk + band * r;
+        uint64_t k = 0;
+        for (int j = 0; j < r; ++j) k |= (uint64_t)sp[j] << (16 * j);
+        keys[(size_t)band * nq + q0 + ql] = k;
+      }
+    }
+  }
+}
+
 // a2 standalone: band keys (band-major) from an int32 signature matrix.
 __global__ __launch_bounds__(256) void band_keys_kernel(const int32_t *__restrict__ sig, int64_t nq, int P,
                                                         int b, int r, uint64_t *__restrict__ keys, int qpb) {
@@ -185,19 +312,30 @@ static int launch_minhash(const int64_t *offsets, const int32_t *rows, int64_t n
                           hipStream_t st) {
   constexpr int VEC = 16 / sizeof(TabT);
   const int lanes = (P_stride + VEC - 1) / VEC;
+  const TabT *tab = static_cast<const TabT *>(perm_t);
+  const dim3 block(256);
+  const size_t smem_group = keys ? (size_t)64 * (P + 2) * 2 : 0;
+  if (lanes <= 64 && smem_group <= 65536) {
+    // group-per-query kernel: 64 queries per workgroup
+    const dim3 grid((unsigned)ceil_div64(nq, 64));
+#define QR_MHG(LPR_)                                                                                            \
+  QR_LAUNCH("minhash", (minhash_group_kernel<TabT, LPR_>), grid, block, smem_group, st, offsets, rows, nq, tab, P, \
+            P_stride, sig, norm2, keys, b, r)
+    if (lanes <= 4) QR_MHG(4);
+    else if (lanes <= 8) QR_MHG(8);
+    else if (lanes <= 16) QR_MHG(16);
+    else if (lanes <= 32) QR_MHG(32);
+    else QR_MHG(64);
+#undef QR_MHG
+    QR_LAUNCH_CHECK("qrlsh_minhash");
+    return QRLSH_OK;
+  }
+  // very long signatures: wave-per-query kernel with a column loop
   const int qpb = pick_qpb(P);
   const size_t smem = keys ? (size_t)qpb * (P + 2) * 2 : 0;
-  const dim3 grid((unsigned)ceil_div64(nq, qpb)), block(256);
-  const TabT *tab = static_cast<const TabT *>(perm_t);
-#define QR_MH(LPR_)                                                                                       \
-  QR_LAUNCH("minhash", (minhash_kernel<TabT, LPR_>), grid, block, smem, st, offsets, rows, nq, tab, P, P_stride, \
-                     sig, norm2, keys, b, r, qpb)
-  if (lanes <= 4) QR_MH(4);
-  else if (lanes <= 8) QR_MH(8);
-  else if (lanes <= 16) QR_MH(16);
-  else if (lanes <= 32) QR_MH(32);
-  else QR_MH(64);
-#undef QR_MH
+  const dim3 grid((unsigned)ceil_div64(nq, qpb));
+  QR_LAUNCH("minhash", (minhash_kernel<TabT, 64>), grid, block, smem, st, offsets, rows, nq, tab, P, P_stride, sig,
+            norm2, keys, b, r, qpb);
   QR_LAUNCH_CHECK("qrlsh_minhash");
   return QRLSH_OK;
 }
