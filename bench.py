@@ -235,7 +235,7 @@ def cpu_leg(nq_s, D, P, b, dev, threads):
     rows = torch.from_numpy(hr).to(dev)
     res = pipeline.query_similarities(off, rows, ops.perm_table(perms, dev), b, K)
     torch.cuda.synchronize()
-    exact = bool(np.array_equal(res.sig.cpu().numpy(), sig)
+    exact = bool(np.array_equal(res.sig_int32().cpu().numpy(), sig)
                  and np.array_equal(res.pairs.cpu().numpy().view(np.uint64), pairs)
                  and np.array_equal(res.milli.cpu().numpy(), milli))
     recall = recall_at_k(s, d, v, res.src.cpu().numpy(), res.dst.cpu().numpy(), res.val.cpu().numpy(), 10)

@@ -38,6 +38,9 @@ extern "C" {
 #define QRLSH_PERM_U16 0 /* permutation table element = uint16 (D <= 65536) */
 #define QRLSH_PERM_I32 1 /* permutation table element = int32 */
 
+#define QRLSH_SIG_I32 0 /* signature rows int32 [nq][P] (the reference's values) */
+#define QRLSH_SIG_U16 1 /* compact rows uint16 [nq][P], 0xFFFF = -1; only valid when D <= 65535 */
+
 #define QRLSH_SORT_MIX 1u  /* radix digits are taken from mix64(key) (grouping sort) */
 #define QRLSH_SORT_IOTA 2u /* first pass synthesises vals = index within the batch */
 
@@ -54,13 +57,15 @@ uint64_t qrlsh_mix64_host(uint64_t x);
  * perm_t : the P permutations TRANSPOSED, [D][P_stride] (row d = the P permuted
  *          indices of table row d), element type perm_dtype; P_stride >= P, and
  *          P_stride * sizeof(element) a multiple of 16.
- * sig_out   [nq][P] int32 (row-major; the reference returns the same matrix as int64)
+ * sig_out   [nq][P] int32 (row-major; the reference returns the same matrix as int64), or NULL
+ * sig16_out [nq][P] uint16 compact rows (0xFFFF = -1), or NULL; needs D <= 65535 and a uint16
+ *           table.  At least one of sig_out / sig16_out.  Half the bytes for qrlsh_score_pairs.
  * norm2_out [nq] int64 = sum_p sig^2 (exact), or NULL          -- feeds qrlsh_score_pairs
  * keys_out  [b][nq] uint64 band keys (see qrlsh_band_keys), or NULL -- fused a2
  */
 int qrlsh_minhash(const int64_t *offsets, const int32_t *rows, int64_t nq, const void *perm_t,
                   int32_t perm_dtype, int32_t P, int32_t P_stride, int32_t D, int32_t *sig_out,
-                  int64_t *norm2_out, uint64_t *keys_out, int32_t b, void *stream);
+                  uint16_t *sig16_out, int64_t *norm2_out, uint64_t *keys_out, int32_t b, void *stream);
 
 /* ---- a2: band keys -----------------------------------------------------------
  * Replaces LSH.make_subvecs / compute_buckets' key construction, lsh.py:17-38:
@@ -129,15 +134,16 @@ int qrlsh_unique_fill(const uint64_t *sorted, int64_t n, const void *workspace, 
  *     np.around(cosine_similarity([sig_i, sig_j])[0][1], 3)
  * computed as exact integer dot / (sqrt(norm2_i) * sqrt(norm2_j)) in float64 (0 if a
  * norm is 0, as sklearn's normalize does), milli = rint(cos * 1000) so that
- * milli / 1000.0 == np.around(cos, 3).
+ * milli / 1000.0 == np.around(cos, 3).  sig is int32 [n][P] (QRLSH_SIG_I32) or the compact
+ * uint16 rows written by qrlsh_minhash (QRLSH_SIG_U16).
  * cos_out (double, unrounded) and edge_out are optional.  edge_out[2n] receives the two
  * directed top-K sort keys of each pair:
  *     src << (id_bits + 11) | (1000 - milli) << id_bits | dst        (needs id_bits <= 26)
  */
 int qrlsh_row_norms(const int32_t *sig, int64_t nq, int32_t P, int64_t *norm2_out, void *stream);
-int qrlsh_score_pairs(const int32_t *sig, const int64_t *norm2, int32_t P, const uint64_t *pairs,
-                      int64_t n, int32_t *milli_out, double *cos_out, uint64_t *edge_out,
-                      int32_t id_bits, void *stream);
+int qrlsh_score_pairs(const void *sig, int32_t sig_dtype, const int64_t *norm2, int32_t P,
+                      const uint64_t *pairs, int64_t n, int32_t *milli_out, double *cos_out,
+                      uint64_t *edge_out, int32_t id_bits, void *stream);
 
 /* ---- a5: per-query top-K -----------------------------------------------------------
  * Replaces argsort(values)[::-1][:K] per query, recommender.py:206-210, on the edge keys

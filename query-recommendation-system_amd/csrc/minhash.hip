@@ -38,14 +38,65 @@ template <typename V> __device__ static inline V vec_shfl_xor(V v, int m) {
   return __builtin_bit_cast(V, x);
 }
 
+// Write one lane's VEC finished values of query q (columns [col, col+VEC)): the int32 row
+// (reference layout), and/or the compact uint16 row (0xFFFF = -1; only when D <= 65535), the
+// low-16 image for the band keys, and the lane's share of the squared norm.
+template <typename TabT>
+__device__ static inline int64_t store_sig(typename TabVec<TabT>::type acc, int n, int64_t q, int col, int P,
+                                           bool vec_store, int32_t *__restrict__ sig, uint16_t *__restrict__ sig16,
+                                           uint16_t *srow) {
+  constexpr int VEC = TabVec<TabT>::N;
+  int32_t out[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) out[e] = (n > 0) ? (int32_t)acc[e] : -1;
+  int64_t nrm = 0;
+  if (vec_store && col + VEC <= P) {
+    if (sig) {
+      int32_t *dst = sig + (size_t)q * P + col;
+#pragma unroll
+      for (int e = 0; e < VEC; e += 4)
+        *reinterpret_cast<i32x4 *>(dst + e) = (i32x4){out[e], out[e + 1], out[e + 2], out[e + 3]};
+    }
+    if (sig16) {
+      uint16_t *d16 = sig16 + (size_t)q * P + col;
+      if (VEC == 8 && (P % 8) == 0) {
+        u16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (uint16_t)out[e % VEC];
+        *reinterpret_cast<u16x8 *>(d16) = v;
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) d16[e] = (uint16_t)out[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) nrm += (int64_t)out[e] * out[e];
+    if (srow) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) srow[col + e] = (uint16_t)out[e];
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e)
+      if (col + e < P) {
+        if (sig) sig[(size_t)q * P + col + e] = out[e];
+        if (sig16) sig16[(size_t)q * P + col + e] = (uint16_t)out[e];
+        nrm += (int64_t)out[e] * out[e];
+        if (srow) srow[col + e] = (uint16_t)out[e];
+      }
+  }
+  return nrm;
+}
+
 // LPR = lanes per table row (power of two); one lane covers VEC = 16 B / sizeof(TabT)
 // permutations; G = 64 / LPR rows are fetched per wave-instruction.
 template <typename TabT, int LPR>
 __global__ __launch_bounds__(256) void minhash_kernel(const int64_t *__restrict__ offsets,
                                                       const int32_t *__restrict__ rows, int64_t nq,
                                                       const TabT *__restrict__ tab, int P, int P_stride,
-                                                      int32_t *__restrict__ sig, int64_t *__restrict__ norm2,
-                                                      uint64_t *__restrict__ keys, int b, int r, int qpb) {
+                                                      int32_t *__restrict__ sig, uint16_t *__restrict__ sig16,
+                                                      int64_t *__restrict__ norm2, uint64_t *__restrict__ keys, int b,
+                                                      int r, int qpb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint16_t *s16 = reinterpret_cast<uint16_t *>(smem_raw);  // [qpb][ldk] low-16 signature image
   using VecT = typename TabVec<TabT>::type;
@@ -83,31 +134,7 @@ __global__ __launch_bounds__(256) void minhash_kernel(const int64_t *__restrict_
 #pragma unroll
       for (int m = LPR; m < WAVE; m <<= 1) acc = __builtin_elementwise_min(acc, vec_shfl_xor(acc, m));
 
-      if (g == 0 && colok) {
-        int32_t out[VEC];
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) out[e] = (n > 0) ? (int32_t)acc[e] : -1;
-        int32_t *dst = sig + (size_t)q * P + col;
-        if (vec_store && col + VEC <= P) {
-#pragma unroll
-          for (int e = 0; e < VEC; e += 4)
-            *reinterpret_cast<i32x4 *>(dst + e) = (i32x4){out[e], out[e + 1], out[e + 2], out[e + 3]};
-#pragma unroll
-          for (int e = 0; e < VEC; ++e) nrm += (int64_t)out[e] * out[e];
-          if (keys) {
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) s16[ql * ldk + col + e] = (uint16_t)out[e];
-          }
-        } else {
-#pragma unroll
-          for (int e = 0; e < VEC; ++e)
-            if (col + e < P) {
-              dst[e] = out[e];
-              nrm += (int64_t)out[e] * out[e];
-              if (keys) s16[ql * ldk + col + e] = (uint16_t)out[e];
-            }
-        }
-      }
+      if (g == 0 && colok) nrm += store_sig<TabT>(acc, n, q, col, P, vec_store, sig, sig16, keys ? s16 + ql * ldk : nullptr);
     }
     if (norm2) {
 #pragma unroll
@@ -144,8 +171,9 @@ template <typename TabT, int LPR>
 __global__ __launch_bounds__(256) void minhash_group_kernel(const int64_t *__restrict__ offsets,
                                                             const int32_t *__restrict__ rows, int64_t nq,
                                                             const TabT *__restrict__ tab, int P, int P_stride,
-                                                            int32_t *__restrict__ sig, int64_t *__restrict__ norm2,
-                                                            uint64_t *__restrict__ keys, int b, int r) {
+                                                            int32_t *__restrict__ sig, uint16_t *__restrict__ sig16,
+                                                            int64_t *__restrict__ norm2, uint64_t *__restrict__ keys,
+                                                            int b, int r) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint16_t *s16 = reinterpret_cast<uint16_t *>(smem_raw);  // [64][ldk] low-16 signature image
   using VecT = typename TabVec<TabT>::type;
@@ -204,31 +232,7 @@ __global__ __launch_bounds__(256) void minhash_group_kernel(const int64_t *__res
     }
     if (q < nq) {
       int64_t nrm = 0;
-      if (colok) {
-        int32_t out[VEC];
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) out[e] = (n_cur > 0) ? (int32_t)acc[e] : -1;
-        int32_t *dst = sig + (size_t)q * P + col;
-        if (vec_store && col + VEC <= P) {
-#pragma unroll
-          for (int e = 0; e < VEC; e += 4)
-            *reinterpret_cast<i32x4 *>(dst + e) = (i32x4){out[e], out[e + 1], out[e + 2], out[e + 3]};
-#pragma unroll
-          for (int e = 0; e < VEC; ++e) nrm += (int64_t)out[e] * out[e];
-          if (keys) {
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) s16[ql * ldk + col + e] = (uint16_t)out[e];
-          }
-        } else {
-#pragma unroll
-          for (int e = 0; e < VEC; ++e)
-            if (col + e < P) {
-              dst[e] = out[e];
-              nrm += (int64_t)out[e] * out[e];
-              if (keys) s16[ql * ldk + col + e] = (uint16_t)out[e];
-            }
-        }
-      }
+      if (colok) nrm = store_sig<TabT>(acc, n_cur, q, col, P, vec_store, sig, sig16, keys ? s16 + ql * ldk : nullptr);
       if (norm2) {
 #pragma unroll
         for (int m = 1; m < LPR; m <<= 1) nrm += __shfl_xor(nrm, m, WAVE);
@@ -308,7 +312,7 @@ static int pick_qpb(int P) {
 
 template <typename TabT>
 static int launch_minhash(const int64_t *offsets, const int32_t *rows, int64_t nq, const void *perm_t, int P,
-                          int P_stride, int32_t *sig, int64_t *norm2, uint64_t *keys, int b, int r,
+                          int P_stride, int32_t *sig, uint16_t *sig16, int64_t *norm2, uint64_t *keys, int b, int r,
                           hipStream_t st) {
   constexpr int VEC = 16 / sizeof(TabT);
   const int lanes = (P_stride + VEC - 1) / VEC;
@@ -320,7 +324,7 @@ static int launch_minhash(const int64_t *offsets, const int32_t *rows, int64_t n
     const dim3 grid((unsigned)ceil_div64(nq, 64));
 #define QR_MHG(LPR_)                                                                                            \
   QR_LAUNCH("minhash", (minhash_group_kernel<TabT, LPR_>), grid, block, smem_group, st, offsets, rows, nq, tab, P, \
-            P_stride, sig, norm2, keys, b, r)
+            P_stride, sig, sig16, norm2, keys, b, r)
     if (lanes <= 4) QR_MHG(4);
     else if (lanes <= 8) QR_MHG(8);
     else if (lanes <= 16) QR_MHG(16);
@@ -335,17 +339,21 @@ static int launch_minhash(const int64_t *offsets, const int32_t *rows, int64_t n
   const size_t smem = keys ? (size_t)qpb * (P + 2) * 2 : 0;
   const dim3 grid((unsigned)ceil_div64(nq, qpb));
   QR_LAUNCH("minhash", (minhash_kernel<TabT, 64>), grid, block, smem, st, offsets, rows, nq, tab, P, P_stride, sig,
-            norm2, keys, b, r, qpb);
+            sig16, norm2, keys, b, r, qpb);
   QR_LAUNCH_CHECK("qrlsh_minhash");
   return QRLSH_OK;
 }
 
 QRLSH_EXPORT int qrlsh_minhash(const int64_t *offsets, const int32_t *rows, int64_t nq, const void *perm_t,
                                int32_t perm_dtype, int32_t P, int32_t P_stride, int32_t D, int32_t *sig_out,
-                               int64_t *norm2_out, uint64_t *keys_out, int32_t b, void *stream) {
+                               uint16_t *sig16_out, int64_t *norm2_out, uint64_t *keys_out, int32_t b,
+                               void *stream) {
   QR_CHECK_ARG(nq >= 0 && P > 0 && D > 0 && P_stride >= P, "qrlsh_minhash: bad sizes nq=%lld P=%d P_stride=%d D=%d",
                (long long)nq, P, P_stride, D);
-  QR_CHECK_ARG(nq == 0 || (offsets && perm_t && sig_out), "qrlsh_minhash: null pointer");
+  QR_CHECK_ARG(nq == 0 || (offsets && perm_t && (sig_out || sig16_out)), "qrlsh_minhash: null pointer");
+  QR_CHECK_ARG(!sig16_out || (D <= 65535 && perm_dtype == QRLSH_PERM_U16),
+               "qrlsh_minhash: the compact uint16 signature needs D <= 65535 and a uint16 table (D=%d)", D);
+  QR_CHECK_ARG(((uintptr_t)sig16_out & 15) == 0, "qrlsh_minhash: 16-B alignment");
   QR_CHECK_ARG(perm_dtype == QRLSH_PERM_U16 || perm_dtype == QRLSH_PERM_I32, "qrlsh_minhash: bad perm_dtype %d",
                perm_dtype);
   const int esz = perm_dtype == QRLSH_PERM_U16 ? 2 : 4;
@@ -365,8 +373,10 @@ QRLSH_EXPORT int qrlsh_minhash(const int64_t *offsets, const int32_t *rows, int6
   if (nq == 0) return QRLSH_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (perm_dtype == QRLSH_PERM_U16)
-    return launch_minhash<uint16_t>(offsets, rows, nq, perm_t, P, P_stride, sig_out, norm2_out, keys_out, b, r, st);
-  return launch_minhash<int32_t>(offsets, rows, nq, perm_t, P, P_stride, sig_out, norm2_out, keys_out, b, r, st);
+    return launch_minhash<uint16_t>(offsets, rows, nq, perm_t, P, P_stride, sig_out, sig16_out, norm2_out, keys_out, b,
+                                    r, st);
+  return launch_minhash<int32_t>(offsets, rows, nq, perm_t, P, P_stride, sig_out, nullptr, norm2_out, keys_out, b, r,
+                                 st);
 }
 
 QRLSH_EXPORT int qrlsh_band_keys(const int32_t *sig, int64_t nq, int32_t P, int32_t b, uint64_t *keys_out,

@@ -14,46 +14,66 @@
 #include "common.h"
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int SCORE_LPP = 16;  // lanes per pair
 
-template <bool VEC4>
-__global__ __launch_bounds__(256) void score_pairs_kernel(const int32_t *__restrict__ sig,
+// value of a compact uint16 signature entry: 0xFFFF is the -1 of an empty answer set
+__device__ static inline int64_t c16(unsigned short v) { return v == 0xFFFFu ? -1 : (int64_t)v; }
+
+// SigT = int32_t (reference layout) or uint16_t (compact rows, D <= 65535: half the HBM bytes)
+template <typename SigT, bool VECLOAD>
+__global__ __launch_bounds__(256) void score_pairs_kernel(const SigT *__restrict__ sig,
                                                           const int64_t *__restrict__ norm2, int P,
                                                           const uint64_t *__restrict__ pairs, int64_t n,
                                                           int32_t *__restrict__ milli, double *__restrict__ cosv,
                                                           uint64_t *__restrict__ edges, int id_bits) {
+  constexpr bool IS16 = sizeof(SigT) == 2;
+  constexpr int VEC = IS16 ? 8 : 4;
   const int lane = threadIdx.x & (WAVE - 1);
   const int lig = lane & (SCORE_LPP - 1);
   const int64_t group = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / SCORE_LPP);
   const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) / SCORE_LPP;
-  // trip count is uniform across the wave: round n up to the groups of one wave
-  const int64_t gpw = WAVE / SCORE_LPP;
-  const int64_t iters = (n + ngroups - 1) / ngroups;
+  const int64_t iters = (n + ngroups - 1) / ngroups;  // uniform trip count for the shuffles
+  // software prefetch of the next pair word
+  uint64_t pr_next = (group < n) ? pairs[group] : 0;
   for (int64_t it = 0; it < iters; ++it) {
     const int64_t t = it * ngroups + group;
     const bool live = t < n;
-    uint64_t pr = 0;
-    if (live) pr = pairs[t];
+    const uint64_t pr = pr_next;
+    const int64_t tn = t + ngroups;
+    pr_next = (tn < n) ? pairs[tn] : 0;
     const uint32_t i = (uint32_t)(pr >> 32), j = (uint32_t)pr;
-    const int32_t *a = sig + (size_t)i * P;
-    const int32_t *c = sig + (size_t)j * P;
+    const SigT *a = sig + (size_t)i * P;
+    const SigT *c = sig + (size_t)j * P;
+    int64_t na = 0, nb = 0;
+    if (live && lig == 0) {
+      na = norm2[i];
+      nb = norm2[j];
+    }
     int64_t dot = 0;
     if (live) {
-      if (VEC4) {
-        for (int col = lig * 4; col < P; col += SCORE_LPP * 4) {
-          const i32x4 x = *reinterpret_cast<const i32x4 *>(a + col);
-          const i32x4 y = *reinterpret_cast<const i32x4 *>(c + col);
-          dot += (int64_t)x.x * y.x + (int64_t)x.y * y.y + (int64_t)x.z * y.z + (int64_t)x.w * y.w;
+      if (VECLOAD) {
+        for (int col = lig * VEC; col < P; col += SCORE_LPP * VEC) {
+          if (IS16) {
+            const u16x8 x = *reinterpret_cast<const u16x8 *>(a + col);
+            const u16x8 y = *reinterpret_cast<const u16x8 *>(c + col);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dot += c16(x[e]) * c16(y[e]);
+          } else {
+            const i32x4 x = *reinterpret_cast<const i32x4 *>(a + col);
+            const i32x4 y = *reinterpret_cast<const i32x4 *>(c + col);
+            dot += (int64_t)x.x * y.x + (int64_t)x.y * y.y + (int64_t)x.z * y.z + (int64_t)x.w * y.w;
+          }
         }
       } else {
-        for (int col = lig; col < P; col += SCORE_LPP) dot += (int64_t)a[col] * c[col];
+        for (int col = lig; col < P; col += SCORE_LPP)
+          dot += IS16 ? c16((unsigned short)a[col]) * c16((unsigned short)c[col]) : (int64_t)a[col] * (int64_t)c[col];
       }
     }
 #pragma unroll
     for (int m = 1; m < SCORE_LPP; m <<= 1) dot += __shfl_xor(dot, m, WAVE);
     if (live && lig == 0) {
-      const int64_t na = norm2[i], nb = norm2[j];
       double cs = 0.0;
       if (na != 0 && nb != 0) cs = (double)dot / (sqrt((double)na) * sqrt((double)nb));
       const int32_t mi = (int32_t)rint(cs * 1000.0);
@@ -65,28 +85,40 @@ __global__ __launch_bounds__(256) void score_pairs_kernel(const int32_t *__restr
         edges[2 * t + 1] = ((uint64_t)j << (id_bits + 11)) | (inv << id_bits) | i;
       }
     }
-    (void)gpw;
   }
 }
 
-QRLSH_EXPORT int qrlsh_score_pairs(const int32_t *sig, const int64_t *norm2, int32_t P, const uint64_t *pairs,
-                                   int64_t n, int32_t *milli_out, double *cos_out, uint64_t *edge_out,
-                                   int32_t id_bits, void *stream) {
+QRLSH_EXPORT int qrlsh_score_pairs(const void *sig, int32_t sig_dtype, const int64_t *norm2, int32_t P,
+                                   const uint64_t *pairs, int64_t n, int32_t *milli_out, double *cos_out,
+                                   uint64_t *edge_out, int32_t id_bits, void *stream) {
   QR_CHECK_ARG(n >= 0 && P > 0, "qrlsh_score_pairs: bad sizes n=%lld P=%d", (long long)n, P);
+  QR_CHECK_ARG(sig_dtype == QRLSH_SIG_I32 || sig_dtype == QRLSH_SIG_U16, "qrlsh_score_pairs: bad sig_dtype %d", sig_dtype);
   if (n == 0) return QRLSH_OK;
   QR_CHECK_ARG(sig && norm2 && pairs && milli_out, "qrlsh_score_pairs: null pointer");
   if (edge_out) QR_CHECK_ARG(id_bits > 0 && id_bits <= 26, "qrlsh_score_pairs: id_bits=%d must be in [1,26]", id_bits);
-  const bool vec4 = (P % 4 == 0) && (((uintptr_t)sig & 15) == 0);
   const int64_t groups_per_block = 256 / SCORE_LPP;
   int64_t blocks = ceil_div64(n, groups_per_block);
   if (blocks > 256 * 32) blocks = 256 * 32;  // grid-stride beyond 32 workgroups per CU
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (vec4)
-    QR_LAUNCH("score_pairs", (score_pairs_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, st, sig, norm2, P, pairs, n,
-                       milli_out, cos_out, edge_out, id_bits);
-  else
-    QR_LAUNCH("score_pairs", (score_pairs_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, st, sig, norm2, P, pairs, n,
-                       milli_out, cos_out, edge_out, id_bits);
+  const dim3 grid((unsigned)blocks), block(256);
+  const bool aligned = (((uintptr_t)sig & 15) == 0);
+  if (sig_dtype == QRLSH_SIG_U16) {
+    const uint16_t *s16 = static_cast<const uint16_t *>(sig);
+    if (aligned && P % 8 == 0)
+      QR_LAUNCH("score_pairs", (score_pairs_kernel<uint16_t, true>), grid, block, 0, st, s16, norm2, P, pairs, n, milli_out,
+                cos_out, edge_out, id_bits);
+    else
+      QR_LAUNCH("score_pairs", (score_pairs_kernel<uint16_t, false>), grid, block, 0, st, s16, norm2, P, pairs, n, milli_out,
+                cos_out, edge_out, id_bits);
+  } else {
+    const int32_t *s32 = static_cast<const int32_t *>(sig);
+    if (aligned && P % 4 == 0)
+      QR_LAUNCH("score_pairs", (score_pairs_kernel<int32_t, true>), grid, block, 0, st, s32, norm2, P, pairs, n, milli_out,
+                cos_out, edge_out, id_bits);
+    else
+      QR_LAUNCH("score_pairs", (score_pairs_kernel<int32_t, false>), grid, block, 0, st, s32, norm2, P, pairs, n, milli_out,
+                cos_out, edge_out, id_bits);
+  }
   QR_LAUNCH_CHECK("qrlsh_score_pairs");
   return QRLSH_OK;
 }

@@ -9,6 +9,8 @@ from .ops import (  # noqa: F401
     perm_table,
     legacy_permutations,
     minhash,
+    can_compact,
+    sig_to_int32,
     band_keys,
     row_norms,
     sort_u64,

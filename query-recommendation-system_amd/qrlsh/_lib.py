@@ -17,6 +17,8 @@ QRLSH_EWORKSPACE = -4
 
 PERM_U16 = 0
 PERM_I32 = 1
+SIG_I32 = 0
+SIG_U16 = 1
 SORT_MIX = 1
 SORT_IOTA = 2
 
@@ -32,7 +34,7 @@ SIGNATURES = {
     "qrlsh_version": (ctypes.c_int, []),
     "qrlsh_last_error": (ctypes.c_char_p, []),
     "qrlsh_mix64_host": (_u64, [_u64]),
-    "qrlsh_minhash": (ctypes.c_int, [_vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
+    "qrlsh_minhash": (ctypes.c_int, [_vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
     "qrlsh_band_keys": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     "qrlsh_sort_workspace_bytes": (_sz, [_i64, _i32]),
     "qrlsh_sort_u64": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _u32, _vp, _sz, _vp]),
@@ -46,7 +48,7 @@ SIGNATURES = {
     "qrlsh_unique_count": (ctypes.c_int, [_vp, _i64, _vp, _sz, _vp, _vp]),
     "qrlsh_unique_fill": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp]),
     "qrlsh_row_norms": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp]),
-    "qrlsh_score_pairs": (ctypes.c_int, [_vp, _vp, _i32, _vp, _i64, _vp, _vp, _vp, _i32, _vp]),
+    "qrlsh_score_pairs": (ctypes.c_int, [_vp, _i32, _vp, _i32, _vp, _i64, _vp, _vp, _vp, _i32, _vp]),
     "qrlsh_topk_count": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _sz, _vp, _vp]),
     "qrlsh_topk_fill": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "qrlsh_prof_enable": (ctypes.c_int, [ctypes.c_int]),

@@ -34,7 +34,7 @@ class HipBackend:
     """libqrlsh kernels (the product path)."""
 
     def minhash(self, offsets, rows, table, b):
-        return ops.minhash(offsets, rows, table, b=b, want_norm=True)
+        return ops.minhash(offsets, rows, table, b=b, want_norm=True, compact=ops.can_compact(table))
 
     def emit_pairs(self, keys, r):
         return ops.emit_pairs_any(keys, r)
@@ -73,6 +73,8 @@ def _staged(t, group):
 
 
 def _all_gather(out, inp, group=None, async_op=False):
+    if inp.dtype == torch.int16:  # compact signature rows: RCCL has no int16, move them as bytes
+        out, inp = out.view(torch.uint8), inp.view(torch.uint8)
     if _staged(inp, group):
         o = torch.empty(out.shape, dtype=out.dtype)
         dist.all_gather_into_tensor(o, inp.cpu(), group=group)
@@ -141,7 +143,7 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
     sig, norm2, keys = be.minhash(offsets, rows, table, b)
 
     # 2. async gather of the signature rows + norms (consumed in step 6)
-    sig_all = torch.empty((nq_total, P), dtype=torch.int32, device=dev)
+    sig_all = torch.empty((nq_total, P), dtype=sig.dtype, device=dev)
     norm_all = torch.empty((nq_total,), dtype=torch.int64, device=dev)
     h_sig = _all_gather(sig_all, sig, group, async_op=True)
     h_nrm = _all_gather(norm_all, norm2, group, async_op=True)

@@ -96,9 +96,24 @@ def perm_table(perms, device="cuda", force_i32=False):
 # ---------------------------------------------------------------------------
 # a1 / a2
 # ---------------------------------------------------------------------------
-def minhash(offsets, rows, table, b=None, want_norm=True):
+def can_compact(table):
+    """compact uint16 signature rows are lossless iff every value < 65535 (0xFFFF encodes -1)"""
+    return table.D <= 65535 and table.code == _lib.PERM_U16
+
+
+def sig_to_int32(sig):
+    """signature tensor (int32, or compact uint16 rows carried as torch.int16) -> int32"""
+    if sig.dtype == torch.int32:
+        return sig
+    v = sig.to(torch.int32) & 0xFFFF
+    return torch.where(v == 0xFFFF, torch.full_like(v, -1), v)
+
+
+def minhash(offsets, rows, table, b=None, want_norm=True, compact=False):
     """sig[q][p] = min over the answer set of perm_p (recommender.py:105-143), -1 if empty.
-    Returns (sig int32 [nq,P], norm2 int64 [nq] | None, keys int64 [b,nq] | None)."""
+    Returns (sig [nq,P], norm2 int64 [nq] | None, keys int64 [b,nq] | None).  sig is int32, or
+    with compact=True (needs can_compact(table)) the uint16 rows (torch.int16 bit patterns,
+    0xFFFF = -1) that qrlsh_score_pairs reads at half the bytes; see sig_to_int32."""
     lib = _lib.load()
     _need(offsets, torch.int64, "offsets", 1)
     _need(rows, torch.int32, "rows", 1)
@@ -109,11 +124,14 @@ def minhash(offsets, rows, table, b=None, want_norm=True):
     dev = offsets.device
     if b is not None and P % b != 0:
         raise AssertionError("signature length %d not divisible by b=%d" % (P, b))  # lsh.py:20
-    sig = torch.empty((nq, P), dtype=torch.int32, device=dev)
+    if compact and not can_compact(table):
+        raise ValueError("compact signatures need D <= 65535")
+    sig = torch.empty((nq, P), dtype=torch.int16 if compact else torch.int32, device=dev)
     norm2 = torch.empty((nq,), dtype=torch.int64, device=dev) if want_norm else None
     keys = torch.empty((b, nq), dtype=torch.int64, device=dev) if b is not None else None
     _lib.check(lib.qrlsh_minhash(_ptr(offsets), _ptr(rows), nq, _ptr(table.tab), table.code, P, table.P_stride,
-                                 table.D, _ptr(sig), _ptr(norm2), _ptr(keys), b if b is not None else 0, _stream()))
+                                 table.D, None if compact else _ptr(sig), _ptr(sig) if compact else None,
+                                 _ptr(norm2), _ptr(keys), b if b is not None else 0, _stream()))
     return sig, norm2, keys
 
 
@@ -284,10 +302,13 @@ def candidate_pairs(keys, r, stats=None):
 # a5: scoring and top-K
 # ---------------------------------------------------------------------------
 def score_pairs(sig, norm2, pairs, want_cos=False, edge_id_bits=None):
-    """milli = rint(1000 * cosine(sig_i, sig_j)) per pair (recommender.py:203-204).
+    """milli = rint(1000 * cosine(sig_i, sig_j)) per pair (recommender.py:203-204).  sig: int32
+    rows or compact uint16 rows (torch.int16).
     Returns (milli int32, cos float64 | None, edges int64 [2n] | None)."""
     lib = _lib.load()
-    _need(sig, torch.int32, "sig", 2)
+    if not isinstance(sig, torch.Tensor) or sig.dtype not in (torch.int32, torch.int16):
+        raise TypeError("sig must be an int32 or int16 (compact) tensor")
+    _need(sig, sig.dtype, "sig", 2)
     _need(norm2, torch.int64, "norm2", 1)
     _need(pairs, torch.int64, "pairs", 1)
     n = pairs.numel()
@@ -295,8 +316,10 @@ def score_pairs(sig, norm2, pairs, want_cos=False, edge_id_bits=None):
     milli = torch.empty((n,), dtype=torch.int32, device=dev)
     cosv = torch.empty((n,), dtype=torch.float64, device=dev) if want_cos else None
     edges = torch.empty((2 * n,), dtype=torch.int64, device=dev) if edge_id_bits is not None else None
-    _lib.check(lib.qrlsh_score_pairs(_ptr(sig), _ptr(norm2), sig.shape[1], _ptr(pairs), n, _ptr(milli), _ptr(cosv),
-                                     _ptr(edges), edge_id_bits if edge_id_bits is not None else 0, _stream()))
+    code = _lib.SIG_U16 if sig.dtype == torch.int16 else _lib.SIG_I32
+    _lib.check(lib.qrlsh_score_pairs(_ptr(sig), code, _ptr(norm2), sig.shape[1], _ptr(pairs), n, _ptr(milli),
+                                     _ptr(cosv), _ptr(edges), edge_id_bits if edge_id_bits is not None else 0,
+                                     _stream()))
     return milli, cosv, edges
 
 

@@ -35,7 +35,7 @@ def select_bands(P, thresh=0.2):
 
 @dataclass
 class HotPathResult:
-    sig: torch.Tensor          # int32 [nq,P]
+    sig: torch.Tensor          # int32 [nq,P], or compact uint16 rows (torch.int16) -- see sig_int32()
     norm2: torch.Tensor        # int64 [nq]
     pairs: torch.Tensor        # int64 [n] sorted unique i<<32|j
     milli: torch.Tensor        # int32 [n]  rint(1000*cos)
@@ -46,8 +46,12 @@ class HotPathResult:
     b: int = 0
     stats: dict = field(default_factory=dict)
 
+    def sig_int32(self):
+        """the signature matrix with the reference's values (int32; -1 = empty answer set)"""
+        return ops.sig_to_int32(self.sig)
 
-def query_similarities(offsets, rows, table, b, K, timings=None):
+
+def query_similarities(offsets, rows, table, b, K, timings=None, compact=None):
     """Whole hot path for the queries described by (offsets, rows) on offsets.device.
 
     table: ops.PermTable (transposed permutations).  Returns HotPathResult; `timings`, when a
@@ -68,7 +72,9 @@ def query_similarities(offsets, rows, table, b, K, timings=None):
         return t0
 
     t0 = time.perf_counter() if timings is not None else 0.0
-    sig, norm2, keys = ops.minhash(offsets, rows, table, b=b, want_norm=True)
+    if compact is None:
+        compact = ops.can_compact(table)   # uint16 signature rows whenever they are lossless
+    sig, norm2, keys = ops.minhash(offsets, rows, table, b=b, want_norm=True, compact=compact)
     t0 = tick("signatures", t0)
     pairs = ops.candidate_pairs(keys, r, stats)
     del keys

@@ -44,6 +44,13 @@ def test_minhash_matches_reference_golden(name, force_i32):
     k2, n2 = ops.band_keys(sig, b, want_norm=True)
     assert torch.equal(k2, keys) and torch.equal(n2, norm2)
     assert torch.equal(ops.row_norms(sig), norm2)
+    if ops.can_compact(table):
+        sig16, n16, k16 = ops.minhash(dev(g["offsets"]), dev(g["rows"]), table, b=b, compact=True)
+        assert sig16.dtype == torch.int16 and torch.equal(ops.sig_to_int32(sig16), sig)
+        assert torch.equal(n16, norm2) and torch.equal(k16, keys)
+    else:
+        with pytest.raises(ValueError):
+            ops.minhash(dev(g["offsets"]), dev(g["rows"]), table, b=b, compact=True)
 
 
 def test_minhash_odd_shapes():
@@ -181,6 +188,10 @@ def test_scores_match_reference_rounding(name):
     m_ref, c_ref = O.score_pairs(g["sig"], pairs_u64(g["pairs"]), mode=1, want_cos=True)
     assert np.array_equal(milli.cpu().numpy(), m_ref)
     assert np.array_equal(cosv.cpu().numpy(), c_ref)  # same correctly-rounded fp64 formula
+    if int(g["D"]) <= 65535:                           # compact uint16 rows: identical scores
+        s16 = dev(np.where(g["sig"] < 0, 0xFFFF, g["sig"]).astype(np.uint16).view(np.int16))
+        m16, c16, _ = ops.score_pairs(s16, norm2, pairs, want_cos=True)
+        assert torch.equal(m16, milli) and torch.equal(c16, cosv)
 
 
 def test_score_non_multiple_of_4_and_zero_rows():
@@ -201,7 +212,7 @@ def test_full_path_matches_reference_tie_aware(name):
     table = ops.perm_table(ops.legacy_permutations(P, D, seed=int(g["seed"])), DEV)
     res = pipeline.query_similarities(dev(g["offsets"]), dev(g["rows"]), table, b, K)
     torch.cuda.synchronize()
-    assert np.array_equal(res.sig.cpu().numpy(), g["sig"])
+    assert np.array_equal(res.sig_int32().cpu().numpy(), g["sig"])
     assert np.array_equal(u64(res.pairs), np.sort(pairs_u64(g["pairs"])))
     check_topk_tie_aware(g, u64(res.pairs), res.milli.cpu().numpy(), res.src.cpu().numpy(), res.dst.cpu().numpy(),
                          res.val.cpu().numpy(), K)
@@ -278,7 +289,7 @@ def test_pipeline_equals_oracle_on_synthetic(nq, D, P, b):
     torch.cuda.synchronize()
     ho, hr = off.cpu().numpy(), rows.cpu().numpy()
     sig = O.minhash(ho, hr, perms)
-    assert np.array_equal(res.sig.cpu().numpy(), sig)
+    assert np.array_equal(res.sig_int32().cpu().numpy(), sig)
     pairs = O.candidates(O.band_keys(sig, b), P // b)
     assert np.array_equal(u64(res.pairs), pairs)
     milli = O.score_pairs(sig, pairs, mode=1)
@@ -314,7 +325,7 @@ def test_full_size_config2_properties_and_oracle():
     # oracle, exact
     ho, hr = off.cpu().numpy(), rows.cpu().numpy()
     sig = O.minhash(ho, hr, perms)
-    assert np.array_equal(res.sig.cpu().numpy(), sig)
+    assert np.array_equal(res.sig_int32().cpu().numpy(), sig)
     opairs = O.candidates(O.band_keys(sig, b), P // b)
     assert np.array_equal(pairs, opairs)
     assert np.array_equal(res.milli.cpu().numpy(), O.score_pairs(sig, opairs, mode=1))
