@@ -43,6 +43,8 @@ extern "C" {
 
 #define QRLSH_SORT_MIX 1u  /* radix digits are taken from mix64(key) (grouping sort) */
 #define QRLSH_SORT_IOTA 2u /* first pass synthesises vals = index within the batch */
+#define QRLSH_SORT_FOLD 4u /* digits from (key >> 32) << w | (key & (2^w - 1)), w = (flags >> 8) & 0xFF:
+                              sorts pairs i << 32 | j over [0, 2w) in ceil(2w / 8) passes */
 
 int qrlsh_version(void);
 const char *qrlsh_last_error(void);

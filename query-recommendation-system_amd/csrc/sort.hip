@@ -27,8 +27,14 @@ __device__ static inline int xcd_tile(int bid, int ntiles) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
 }
 
-template <bool MIX> __device__ static inline uint32_t digit_of(uint64_t key, int shift) {
-  const uint64_t x = MIX ? qr_mix64(key) : key;
+// digit source: MODE 0 = the key itself, 1 = mix64(key) (grouping sort), 2 = the key with its
+// two 32-bit halves packed next to each other, hi << fold | lo (pairs i << 32 | j sort in
+// ceil(2*id_bits / 8) passes instead of 2 * ceil(id_bits / 8)).
+enum { SM_PLAIN = 0, SM_MIX = 1, SM_FOLD = 2 };
+template <int MODE> __device__ static inline uint32_t digit_of(uint64_t key, int shift, int fold = 0) {
+  uint64_t x = key;
+  if (MODE == SM_MIX) x = qr_mix64(key);
+  if (MODE == SM_FOLD) x = ((key >> 32) << fold) | (key & ((1ull << fold) - 1ull));
   return (uint32_t)(x >> shift) & (RADIX - 1);
 }
 
@@ -37,14 +43,15 @@ template <bool MIX> __device__ static inline uint32_t digit_of(uint64_t key, int
 // landing in one part, so a data set with many empty answer sets cannot overflow a part.
 template <bool SPREAD> __device__ static inline uint32_t part_digit(uint64_t key, int64_t idx, int shift, uint64_t ek) {
   if (SPREAD && key == ek) return (uint32_t)(qr_mix64((uint64_t)idx) >> 56) & (RADIX - 1);
-  return digit_of<true>(key, shift);
+  return digit_of<SM_MIX>(key, shift);
 }
 
 // ghist layout: [batch][digit][tile]
-template <bool MIX, bool SPREAD = false>
+template <int MIX, bool SPREAD = false>
 __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const uint64_t *__restrict__ keys, int64_t n,
                                                                  int ntiles, int shift,
-                                                                 uint32_t *__restrict__ ghist, uint64_t ek = 0) {
+                                                                 uint32_t *__restrict__ ghist, uint64_t ek = 0,
+                                                                 int fold = 0) {
   __shared__ uint32_t h[RADIX];
   const int tile = blockIdx.x, batch = blockIdx.y;
   h[threadIdx.x] = 0;
@@ -54,7 +61,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const uint64_t 
 #pragma unroll
   for (int i = 0; i < SORT_IPT; ++i) {
     const int64_t idx = base + (int64_t)i * SORT_THREADS + threadIdx.x;
-    if (idx < n) atomicAdd(&h[SPREAD ? part_digit<SPREAD>(k[idx], idx, shift, ek) : digit_of<MIX>(k[idx], shift)], 1u);
+    if (idx < n) atomicAdd(&h[SPREAD ? part_digit<SPREAD>(k[idx], idx, shift, ek) : digit_of<MIX>(k[idx], shift, fold)], 1u);
   }
   __syncthreads();
   ghist[((size_t)batch * RADIX + threadIdx.x) * ntiles + tile] = h[threadIdx.x];
@@ -95,7 +102,7 @@ __global__ __launch_bounds__(256) void sort_rowscan_kernel(uint32_t *__restrict_
   if (t == 0) rtot[(size_t)batch * RADIX + d] = carry;
 }
 
-template <bool MIX, bool HAS_VAL, bool IOTA, bool SPREAD = false>
+template <int MIX, bool HAS_VAL, bool IOTA, bool SPREAD = false>
 __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const uint64_t *__restrict__ keys_in,
                                                                     const uint32_t *__restrict__ vals_in,
                                                                     uint64_t *__restrict__ keys_out,
@@ -103,7 +110,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const uint64
                                                                     int ntiles, int shift,
                                                                     const uint32_t *__restrict__ goff,
                                                                     const uint32_t *__restrict__ rtot,
-                                                                    uint64_t ek = 0) {
+                                                                    uint64_t ek = 0, int fold = 0) {
   __shared__ uint32_t cnt[SORT_THREADS / WAVE][RADIX];
   __shared__ uint32_t dsum[SORT_THREADS / WAVE];
   const int tile = xcd_tile(blockIdx.x, ntiles), batch = blockIdx.y;
@@ -130,7 +137,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const uint64
   for (int k = 0; k < SORT_IPT; ++k) {
     const int64_t idx = wbase + (int64_t)k * WAVE + lane;
     const bool valid = idx < n;
-    const uint32_t d = SPREAD ? part_digit<SPREAD>(key[k], idx, shift, ek) : digit_of<MIX>(key[k], shift);
+    const uint32_t d = SPREAD ? part_digit<SPREAD>(key[k], idx, shift, ek) : digit_of<MIX>(key[k], shift, fold);
     uint64_t m = __ballot(valid);
 #pragma unroll
     for (int bit = 0; bit < 8; ++bit) {
@@ -191,9 +198,9 @@ QRLSH_EXPORT size_t qrlsh_sort_workspace_bytes(int64_t n, int32_t nbatch) {
   return (size_t)nbatch * RADIX * (ntiles + 1) * sizeof(uint32_t);
 }
 
-template <bool MIX>
+template <int MIX>
 static int sort_passes(uint64_t *ka, uint64_t *kb, uint32_t *va, uint32_t *vb, int64_t n, int nbatch, int bit_lo,
-                       int bit_hi, bool iota, uint32_t *ghist, hipStream_t st) {
+                       int bit_hi, bool iota, int fold, uint32_t *ghist, hipStream_t st) {
   const int ntiles = (int)ceil_div64(n, SORT_TILE);
   const dim3 grid(ntiles, nbatch), block(SORT_THREADS);
   const bool has_val = va != nullptr;
@@ -202,17 +209,17 @@ static int sort_passes(uint64_t *ka, uint64_t *kb, uint32_t *va, uint32_t *vb, i
   for (int shift = bit_lo; shift < bit_hi; shift += 8) {
     uint64_t *kin = cur ? kb : ka, *kout = cur ? ka : kb;
     uint32_t *vin = cur ? vb : va, *vout = cur ? va : vb;
-    QR_LAUNCH("sort_hist", (sort_hist_kernel<MIX>), grid, block, 0, st, kin, n, ntiles, shift, ghist);
+    QR_LAUNCH("sort_hist", (sort_hist_kernel<MIX>), grid, block, 0, st, kin, n, ntiles, shift, ghist, (uint64_t)0, fold);
     QR_LAUNCH("sort_rowscan", sort_rowscan_kernel, dim3(RADIX, nbatch), dim3(256), 0, st, ghist, ntiles, rtot);
     if (!has_val)
       QR_LAUNCH("sort_scatter_k", (sort_scatter_kernel<MIX, false, false>), grid, block, 0, st, kin, vin, kout, vout, n,
-                         ntiles, shift, ghist, rtot);
+                         ntiles, shift, ghist, rtot, (uint64_t)0, fold);
     else if (iota && shift == bit_lo)
       QR_LAUNCH("sort_scatter_kv", (sort_scatter_kernel<MIX, true, true>), grid, block, 0, st, kin, vin, kout, vout, n,
-                         ntiles, shift, ghist, rtot);
+                         ntiles, shift, ghist, rtot, (uint64_t)0, fold);
     else
       QR_LAUNCH("sort_scatter_kv", (sort_scatter_kernel<MIX, true, false>), grid, block, 0, st, kin, vin, kout, vout, n,
-                         ntiles, shift, ghist, rtot);
+                         ntiles, shift, ghist, rtot, (uint64_t)0, fold);
     cur ^= 1;
   }
   hipError_t e = hipGetLastError();
@@ -243,8 +250,13 @@ QRLSH_EXPORT int qrlsh_sort_u64(uint64_t *keys_a, uint64_t *keys_b, uint32_t *va
   uint32_t *ghist = static_cast<uint32_t *>(workspace);
   const bool iota = (flags & QRLSH_SORT_IOTA) != 0;
   if (flags & QRLSH_SORT_MIX)
-    return sort_passes<true>(keys_a, keys_b, vals_a, vals_b, n, nbatch, bit_lo, bit_hi, iota, ghist, st);
-  return sort_passes<false>(keys_a, keys_b, vals_a, vals_b, n, nbatch, bit_lo, bit_hi, iota, ghist, st);
+    return sort_passes<SM_MIX>(keys_a, keys_b, vals_a, vals_b, n, nbatch, bit_lo, bit_hi, iota, 0, ghist, st);
+  if (flags & QRLSH_SORT_FOLD) {
+    const int fold = (int)((flags >> 8) & 0xFF);
+    QR_CHECK_ARG(fold >= 1 && fold <= 32, "qrlsh_sort_u64: fold width %d not in [1,32]", fold);
+    return sort_passes<SM_FOLD>(keys_a, keys_b, vals_a, vals_b, n, nbatch, bit_lo, bit_hi, iota, fold, ghist, st);
+  }
+  return sort_passes<SM_PLAIN>(keys_a, keys_b, vals_a, vals_b, n, nbatch, bit_lo, bit_hi, iota, 0, ghist, st);
 }
 
 // ==========================================================================================
@@ -422,9 +434,9 @@ QRLSH_EXPORT int qrlsh_bucket_pairs_count(const uint64_t *keys, uint64_t *part_k
   const dim3 grid(ntiles, b), block(SORT_THREADS);
   const int shift = 56;
   const uint64_t ek = qr_empty_key(r);
-  QR_LAUNCH("sort_hist", (sort_hist_kernel<true, true>), grid, block, 0, st, keys, nq, ntiles, shift, ghist, ek);
+  QR_LAUNCH("sort_hist", (sort_hist_kernel<SM_MIX, true>), grid, block, 0, st, keys, nq, ntiles, shift, ghist, ek);
   QR_LAUNCH("sort_rowscan", sort_rowscan_kernel, dim3(RADIX, b), dim3(256), 0, st, ghist, ntiles, rtot);
-  QR_LAUNCH("sort_scatter_kv", (sort_scatter_kernel<true, true, true, true>), grid, block, 0, st, keys,
+  QR_LAUNCH("sort_scatter_kv", (sort_scatter_kernel<SM_MIX, true, true, true>), grid, block, 0, st, keys,
             (const uint32_t *)nullptr, part_keys, part_ids, nq, ntiles, shift, ghist, rtot, ek);
   QR_LAUNCH("bucket_count", (bucket_finish_kernel<false>), dim3(RADIX, b), dim3(FIN_THREADS), 0, st, part_keys, part_ids,
             nq, rtot, qr_empty_key(r), blk, reinterpret_cast<uint32_t *>(total_overflow_out + 1), (uint64_t *)nullptr);

@@ -21,6 +21,7 @@ SIG_I32 = 0
 SIG_U16 = 1
 SORT_MIX = 1
 SORT_IOTA = 2
+SORT_FOLD = 4
 
 _vp = ctypes.c_void_p
 _i32 = ctypes.c_int32

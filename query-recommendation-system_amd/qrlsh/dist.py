@@ -40,8 +40,9 @@ class HipBackend:
         return ops.emit_pairs_any(keys, r)
 
     def sort_unique(self, words, bit_ranges):
-        for lo, hi in bit_ranges:
-            words, _ = ops.sort_u64(words, None, lo, hi)
+        # bit_ranges = [(0, ib), (32, 32 + ib)]: pair words i << 32 | j
+        ib = bit_ranges[0][1]
+        words, _ = ops.sort_u64(words, None, 0, 2 * ib, fold=ib)
         return ops.unique_sorted(words)
 
     def sort_words(self, words, lo, hi):

@@ -160,7 +160,7 @@ def row_norms(sig):
 # ---------------------------------------------------------------------------
 # radix sort
 # ---------------------------------------------------------------------------
-def sort_u64(keys, vals=None, bit_lo=0, bit_hi=64, mix=False, iota=False):
+def sort_u64(keys, vals=None, bit_lo=0, bit_hi=64, mix=False, iota=False, fold=0):
     """Stable LSD radix sort of each row of keys (int64 bit patterns, unsigned order) over
     bits [bit_lo, bit_hi) (of mix64(key) when mix).  `keys` (and vals) are consumed as one
     of the two ping-pong buffers.  Returns (sorted_keys, sorted_vals | None)."""
@@ -179,6 +179,8 @@ def sort_u64(keys, vals=None, bit_lo=0, bit_hi=64, mix=False, iota=False):
     nbytes = lib.qrlsh_sort_workspace_bytes(n, nbatch)
     ws = _ws(nbytes, keys.device)
     flags = (_lib.SORT_MIX if mix else 0) | (_lib.SORT_IOTA if iota else 0)
+    if fold:
+        flags |= _lib.SORT_FOLD | (int(fold) << 8)
     rc = _lib.check(lib.qrlsh_sort_u64(_ptr(k2), _ptr(kb), _ptr(vals), _ptr(vb), n, nbatch, bit_lo, bit_hi, flags,
                                        _ptr(ws), ws.numel(), _stream()))
     ko = kb if rc == 1 else k2
@@ -247,8 +249,7 @@ def unique_sorted(a):
 def sort_pairs(pairs, nq):
     """sort i<<32|j words: LSD over j's bits, then i's bits"""
     ib = id_bits_for(nq)
-    p, _ = sort_u64(pairs, None, 0, ib)
-    p, _ = sort_u64(p, None, 32, 32 + ib)
+    p, _ = sort_u64(pairs, None, 0, 2 * ib, fold=ib)   # digits of i << ib | j: ceil(2 ib / 8) passes
     return p
 
 

@@ -100,6 +100,14 @@ def test_radix_sort_matches_numpy_stable(n, nbatch):
         # keys only
         ks2, none = ops.sort_u64(dev(k.view(np.int64)), None, lo, hi)
         assert none is None and torch.equal(ks2, ks)
+    # folded digits: pair words i << 32 | j ordered as i << w | j
+    for w in (5, 20, 27):
+        i = rng.integers(0, 2 ** w, size=(nbatch, n), dtype=np.uint64)
+        j = rng.integers(0, 2 ** w, size=(nbatch, n), dtype=np.uint64)
+        k = (i << np.uint64(32)) | j
+        ks, _ = ops.sort_u64(dev(k.view(np.int64)), None, 0, 2 * w, fold=w)
+        for bi in range(nbatch):
+            assert np.array_equal(u64(ks)[bi], np.sort(k[bi]))
 
 
 def test_mix_sort_groups_equal_keys():
