@@ -45,18 +45,49 @@ def parse():
     return ap.parse_args()
 
 
-def algorithmic_bytes(label, w):
-    """Algorithmic HBM bytes of ONE launch of a kernel label on workload w (SURVEY.md 8d;
-    int32 signatures, uint64 keys, 8-byte pairs).  Returns (bytes, unit description)."""
+def algorithmic_bytes_per_step(w):
+    """Algorithmic HBM bytes each kernel label moves in ONE step of workload w (DESIGN.md section 4:
+    what the stage must read and write once, with this build's layouts -- compact uint16 signature
+    rows when D <= 65535, uint64 keys, 8-byte pairs and edge keys).  Labels = the names the
+    library's HIP-event profiler and tools/summarise_profile.py use."""
     nq, P, b, nnz = w["nq"], w["P"], w["b"], w["nnz"]
-    if label == "minhash":
-        # read CSR (4 B/row id + 8 B offset), write sig (4P) + fused band keys (8b) + norm (8)
-        return 4 * nnz + 8 * nq + (4 * P + 8 * b + 8) * nq
-    if label == "sort_hist":
-        return None  # depends on which sort; filled by caller
-    if label == "score_pairs":
-        return (8 * P + 16) * w["unique_pairs"]
-    return None
+    em, un, kept = w["emitted"], w["unique"], w["kept"]
+    sb = w["sig_bytes"]
+    rec = b * w["nq_sorted"]                      # (band, query) records this rank buckets
+    ib = max(1, (w["nq_total"] - 1).bit_length())
+    pair_passes = -(-2 * ib // 8)
+    edge_passes = -(-(ib + 11) // 8)
+    out = {
+        # CSR in (4 B/row id + 8 B offset); signature row, fused band keys and norm out
+        "minhash": 4 * nnz + 8 * nq + (sb * P + 8 * b + 8) * nq,
+        # partition pass of the bucket path: key in, key + id out
+        "sort_scatter_kv": (8 + 12) * rec,
+        "bucket_count": 12 * rec,
+        "bucket_fill": 12 * rec + 8 * em,
+        # keys-only LSD passes: pair words, then directed edge keys
+        "sort_scatter_k": 16 * (pair_passes * em + edge_passes * 2 * un),
+        "sort_hist": 8 * (rec + pair_passes * em + edge_passes * 2 * un),
+        "unique_count": 8 * em,
+        "unique_fill": 8 * em + 8 * un,
+        # two signature rows + pair word in; score + two edge keys out
+        "score_pairs": (2 * sb * P + 8 + 4 + 16) * un,
+        "topk_count": 8 * 2 * un,
+        "topk_fill": 8 * 2 * un + 12 * kept,
+    }
+    return out
+
+
+def load_traffic():
+    """PMC-derived HBM bytes per launch per label (profiles/*_hbm_traffic.json, written by
+    tools/summarise_profile.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
+    if not files:
+        return {}, None
+    try:
+        return json.load(open(files[-1])).get("by_label", {}), os.path.basename(files[-1])
+    except Exception:
+        return {}, None
 
 
 def main():
@@ -132,39 +163,34 @@ def main():
 
     out = None
     if rank == 0:
-        w = dict(nq=nq_local, P=P, b=b, nnz=nnz, unique_pairs=int(res.pairs.numel()))
+        w = dict(nq=nq_local, nq_total=nq_total, nq_sorted=nq_local,
+                 P=P, b=b, nnz=nnz, emitted=int(res.stats.get("emitted_pairs", 0)), unique=int(res.pairs.numel()),
+                 kept=int(res.src.numel()), sig_bytes=2 if res.sig.dtype == torch.int16 else 4)
+        ab = algorithmic_bytes_per_step(w)
+        traffic, traffic_src = load_traffic()
         kernels = {}
         for name, (cnt_, ms) in prof.items():
-            kernels[name] = {"launches_per_step": cnt_ / args.steps, "ms_per_step": ms / args.steps,
-                             "avg_ms": ms / cnt_}
+            k = {"launches_per_step": cnt_ / args.steps, "ms_per_step": ms / args.steps, "avg_ms": ms / cnt_}
+            if name in ab and ms > 0:
+                k["algorithmic_bytes_per_step"] = ab[name]
+                k["algorithmic_GBps"] = round(ab[name] / (ms / args.steps * 1e-3) / 1e9, 1)
+            kernels[name] = k
         roofline = None
         if kernels:
             dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
-            # records moved by one launch of each sort kernel in the bucket sort (the big one): b*nq
-            per_launch = {
-                "minhash": algorithmic_bytes("minhash", w),
-                "score_pairs": algorithmic_bytes("score_pairs", w),
-                # bucket sort dominates the sort_* labels: (key 8 + id 4) read + write per record
-                "sort_scatter_kv": 24 * b * nq_local * (world if world > 1 else 1) // max(world, 1),
-                "sort_hist": None,
-                "sort_scatter_k": None,
-            }
-            ab = per_launch.get(dom)
-            avg_ms = kernels[dom]["avg_ms"]
-            if ab is not None:
-                achieved = ab / (avg_ms * 1e-3) / 1e9
-                roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                            "algorithmic_bytes_per_launch": ab, "avg_launch_ms": round(avg_ms, 4),
-                            "launches_per_step": kernels[dom]["launches_per_step"]}
-            else:
-                roofline = {"kernel": dom, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": None, "traffic": None, "avg_launch_ms": round(avg_ms, 4),
-                            "launches_per_step": kernels[dom]["launches_per_step"]}
-            # per-kernel achieved GB/s for the kernels with a closed-form byte count
-            for kname in ("minhash", "score_pairs", "sort_scatter_kv"):
-                if kname in kernels and per_launch.get(kname):
-                    kernels[kname]["algorithmic_GBps"] = round(per_launch[kname] / (kernels[kname]["avg_ms"] * 1e-3) / 1e9, 1)
+            kd = kernels[dom]
+            lps = kd["launches_per_step"]
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": None, "traffic": None, "avg_launch_ms": round(kd["avg_ms"], 4),
+                        "launches_per_step": lps}
+            if dom in ab:
+                per_launch = ab[dom] / lps
+                achieved = per_launch / (kd["avg_ms"] * 1e-3) / 1e9
+                roofline.update({"achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBS, 4),
+                                 "algorithmic_bytes_per_launch": int(per_launch)})
+            if dom in traffic:
+                roofline["traffic"] = int(traffic[dom]["hbm_bytes_per_launch"])
+                roofline["traffic_source"] = traffic_src
 
         cpu_baseline = None
         recall = None
@@ -182,7 +208,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "int32 signatures / uint64 keys (integer); float64 cosine",
+            "dtype": "u16/int32 MinHash values, uint64 keys and pairs (integer); float64 cosine",
             "data": "synthetic (clustered answer sets, SURVEY 8d recipe; seed 0; permutation seed 42)",
             "config": {"workload": "configs[1]: %d queries/GPU x %d-perm MinHash, %d bands, D=%d, K=%d, mean |A(q)|=%.2f"
                        % (nq_local, P, b, D, K, nnz / nq_local),

@@ -293,7 +293,7 @@ __device__ static inline uint32_t fin_slot(uint64_t key) {
 // write a pair (fill reads them from global memory, L2-hot).  LDS image: keys 48 KB + heads
 // 16 KB + links 12 KB = 76 KB -> two workgroups per CU.
 template <bool FILL>
-__global__ __launch_bounds__(FIN_THREADS) void bucket_finish_kernel(const uint64_t *__restrict__ keys,
+__global__ __launch_bounds__(FIN_THREADS, 8) void bucket_finish_kernel(const uint64_t *__restrict__ keys,
                                                                     const uint32_t *__restrict__ ids, int64_t nq,
                                                                     const uint32_t *__restrict__ rtot, uint64_t ek,
                                                                     uint64_t *__restrict__ blk,
@@ -339,11 +339,14 @@ __global__ __launch_bounds__(FIN_THREADS) void bucket_finish_kernel(const uint64
   }
   for (int i = tid; i < FIN_HT; i += FIN_THREADS) head[i] = 0xFFFFFFFFu;
   const uint64_t *k = keys + (size_t)band * nq + start;
+  const uint32_t *id = ids + (size_t)band * nq + start;
   uint64_t kreg[FIN_IPT];
+  uint32_t ireg[FIN_IPT];
 #pragma unroll
   for (int j = 0; j < FIN_IPT; ++j) {
     const uint32_t i = tid + j * FIN_THREADS;
     kreg[j] = i < m ? k[i] : ek;
+    if (FILL) ireg[j] = i < m ? id[i] : 0u;  // coalesced, in flight together with the keys
   }
 #pragma unroll
   for (int j = 0; j < FIN_IPT; ++j) {
@@ -361,16 +364,21 @@ __global__ __launch_bounds__(FIN_THREADS) void bucket_finish_kernel(const uint64
   __syncthreads();
 
   uint32_t c[FIN_IPT];
+  uint32_t m12[FIN_IPT];  // FILL: positions of the first two matches, u1 | u2 << 16
   uint64_t mine = 0;
 #pragma unroll
   for (int j = 0; j < FIN_IPT; ++j) {
     const uint32_t i = tid + j * FIN_THREADS;
-    uint32_t cnt = 0;
+    uint32_t cnt = 0, mm = 0;
     if (kreg[j] != ek) {
       for (uint32_t u = head[slot[j]] & 0xFFFFu; u != FIN_NIL; u = nxt[u])
-        if (u < i && sk[u] == kreg[j]) ++cnt;
+        if (u < i && sk[u] == kreg[j]) {
+          if (FILL && cnt < 2) mm |= u << (16 * cnt);
+          ++cnt;
+        }
     }
     c[j] = cnt;
+    m12[j] = mm;
     mine += cnt;
   }
   // block exclusive scan over 1024 threads
@@ -388,15 +396,47 @@ __global__ __launch_bounds__(FIN_THREADS) void bucket_finish_kernel(const uint64
     if (tid == 0) blk[(size_t)band * RADIX + part] = tot;
     return;
   }
-  const uint32_t *id = ids + (size_t)band * nq + start;
-  uint64_t pos = blk[(size_t)band * RADIX + part] + base + inc - mine;
+  // Emission without a global load inside a chain walk.  The ids came in with the keys
+  // (registers); once every walk is over the key image is dead and its space holds the ids of
+  // all records, so a match position u turns into a query id with one LDS read.  Matches beyond
+  // the second of a record (buckets of 4+) are rare: a second walk, done while the keys are
+  // still in LDS, writes them straight out with a global id gather.
+  const uint64_t pos0 = blk[(size_t)band * RADIX + part] + base + inc - mine;
+  {
+    uint64_t pos = pos0;
+#pragma unroll
+    for (int j = 0; j < FIN_IPT; ++j) {
+      if (c[j] > 2) {
+        const uint32_t i = tid + j * FIN_THREADS;
+        uint32_t seen = 0;
+        for (uint32_t u = head[slot[j]] & 0xFFFFu; u != FIN_NIL; u = nxt[u])
+          if (u < i && sk[u] == kreg[j]) {
+            if (seen >= 2) out[pos + seen] = ((uint64_t)id[u] << 32) | ireg[j];
+            ++seen;
+          }
+      }
+      pos += c[j];
+    }
+  }
+  __syncthreads();  // all walks done: sk is free
+  uint32_t *si = reinterpret_cast<uint32_t *>(sk);
 #pragma unroll
   for (int j = 0; j < FIN_IPT; ++j) {
-    if (c[j] == 0) continue;
     const uint32_t i = tid + j * FIN_THREADS;
-    const uint32_t myid = id[i];
-    for (uint32_t u = head[slot[j]] & 0xFFFFu; u != FIN_NIL; u = nxt[u])
-      if (u < i && sk[u] == kreg[j]) out[pos++] = ((uint64_t)id[u] << 32) | myid;
+    if (i < m) si[i] = ireg[j];
+  }
+  __syncthreads();
+  {
+    uint64_t pos = pos0;
+#pragma unroll
+    for (int j = 0; j < FIN_IPT; ++j) {
+      if (c[j] != 0) {
+        const uint64_t lo = ireg[j];
+        out[pos] = ((uint64_t)si[m12[j] & 0xFFFFu] << 32) | lo;
+        if (c[j] > 1) out[pos + 1] = ((uint64_t)si[m12[j] >> 16] << 32) | lo;
+      }
+      pos += c[j];
+    }
   }
 }
 

@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libqrlsh.so")
+LIB_PATH = os.environ.get("QRLSH_LIB", os.path.join(_HERE, "libqrlsh.so"))  # QRLSH_LIB: development override
 
 QRLSH_OK = 0
 QRLSH_EINVAL = -1

@@ -24,6 +24,26 @@ def short(name):
     return base + (m.group(2) or "")
 
 
+# rocprof kernel name -> the label the library's HIP-event profiler (and bench.py) uses
+LABELS = [
+    (r"^minhash_", "minhash"), (r"^band_keys_kernel", "band_keys"), (r"^row_norms_kernel", "row_norms"),
+    (r"^sort_hist_kernel", "sort_hist"), (r"^sort_rowscan_kernel", "sort_rowscan"),
+    (r"^sort_scatter_kernel<\d+, false", "sort_scatter_k"), (r"^sort_scatter_kernel<\d+, true", "sort_scatter_kv"),
+    (r"^bucket_finish_kernel<false>", "bucket_count"), (r"^bucket_finish_kernel<true>", "bucket_fill"),
+    (r"^pairs_count_kernel", "pairs_count"), (r"^pairs_fill_kernel", "pairs_fill"),
+    (r"^compact_count_kernel<0>", "unique_count"), (r"^compact_fill_kernel<0>", "unique_fill"),
+    (r"^compact_count_kernel<1>", "topk_count"), (r"^compact_fill_kernel<1>", "topk_fill"),
+    (r"^score_pairs_kernel", "score_pairs"), (r"^scan_u64_kernel", "scan_blocks"), (r"^synth_kernel", "synth"),
+]
+
+
+def label_of(kname):
+    for pat, lab in LABELS:
+        if re.search(pat, kname):
+            return lab
+    return None
+
+
 def pmc(dirname, counter):
     f = glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True)
     acc = defaultdict(list)
@@ -64,7 +84,20 @@ def main():
             traffic[k] = {"launches": max(len(fetch.get(k, [])), len(write.get(k, []))),
                           "read_bytes": rb, "write_bytes": wb, "hbm_bytes": rb + wb}
             w.writerow([k, traffic[k]["launches"], "%.1f" % f, "%.1f" % wr, "%.0f" % rb, "%.0f" % wb, "%.0f" % (rb + wb)])
-    json.dump(traffic, open(os.path.join(out, tag + "_hbm_traffic.json"), "w"), indent=1, sort_keys=True)
+    by_label = {}
+    for k, t in traffic.items():
+        lab = label_of(k)
+        if lab is None:
+            continue
+        e = by_label.setdefault(lab, {"launches": 0, "bytes": 0.0})
+        e["launches"] += t["launches"]
+        e["bytes"] += t["hbm_bytes"] * t["launches"]
+    for lab, e in by_label.items():
+        e["hbm_bytes_per_launch"] = e.pop("bytes") / max(e["launches"], 1)
+    json.dump({"by_kernel": traffic, "by_label": by_label,
+               "note": "FETCH_SIZE(KB)*1024*2 (gfx950 half-count correction) + WRITE_SIZE(KB)*1024, averaged per launch; "
+                       "separate rocprofv3 --pmc passes"},
+              open(os.path.join(out, tag + "_hbm_traffic.json"), "w"), indent=1, sort_keys=True)
     print("wrote profiles/%s_*" % tag)
 
 
