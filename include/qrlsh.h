@@ -110,19 +110,23 @@ int qrlsh_pairs_fill(const uint64_t *sorted_keys, const uint32_t *sorted_ids, in
                      void *stream);
 
 /* Fast form of the same step for keys straight from qrlsh_minhash / qrlsh_band_keys (band-major
- * [b][nq], NOT sorted): one radix partition pass on the top 8 bits of mix64(key) into
- * part_keys / part_ids, then an LDS hash-group finish per (part, band).  count leaves
- * {total pairs, overflow flag} in total_overflow_out[2] (device uint64 x2); overflow != 0 means a
- * part exceeded the LDS image (heavily skewed data): ignore the total and use the general path
+ * [b][nq], NOT sorted): radix partition on the top part_bits (8..16) bits of mix64(key) -- one
+ * pass for 8 bits, two above (tmp_keys / tmp_ids are the intermediate buffers, may be NULL for
+ * 8) -- into part_keys / part_ids, then an LDS hash-group finish per (part, band).  Pick
+ * part_bits so that nq / 2^part_bits is ~2-4 K.  count leaves {total pairs, overflow flag} in
+ * total_overflow_out[2] (device uint64 x2); overflow != 0 means a part exceeded the LDS image
+ * (6144 records; heavily skewed data): ignore the total and use the general path
  * (qrlsh_sort_u64 + qrlsh_pairs_count/fill) instead.  fill must follow a count on the same
  * workspace.  Same pairs as the general path, in a different (still duplicate-carrying) order.
  */
-size_t qrlsh_bucket_workspace_bytes(int64_t nq, int32_t b);
-int qrlsh_bucket_pairs_count(const uint64_t *keys, uint64_t *part_keys, uint32_t *part_ids, int64_t nq,
-                             int32_t b, int32_t r, void *workspace, size_t workspace_bytes,
+size_t qrlsh_bucket_workspace_bytes(int64_t nq, int32_t b, int32_t part_bits);
+int qrlsh_bucket_pairs_count(const uint64_t *keys, uint64_t *part_keys, uint32_t *part_ids,
+                             uint64_t *tmp_keys, uint32_t *tmp_ids, int64_t nq, int32_t b, int32_t r,
+                             int32_t part_bits, void *workspace, size_t workspace_bytes,
                              uint64_t *total_overflow_out, void *stream);
 int qrlsh_bucket_pairs_fill(const uint64_t *part_keys, const uint32_t *part_ids, int64_t nq, int32_t b,
-                            int32_t r, void *workspace, uint64_t *pairs_out, void *stream);
+                            int32_t r, int32_t part_bits, void *workspace, uint64_t *pairs_out,
+                            void *stream);
 
 /* unique of a sorted uint64 array (count-then-fill) */
 size_t qrlsh_compact_workspace_bytes(int64_t n);

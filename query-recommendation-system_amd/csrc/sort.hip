@@ -41,9 +41,10 @@ template <int MODE> __device__ static inline uint32_t digit_of(uint64_t key, int
 // Partition digit of the fast bucket path: records holding the "empty" key (all -1 band,
 // never a candidate: lsh.py:47) are dealt round the parts by their index instead of all
 // landing in one part, so a data set with many empty answer sets cannot overflow a part.
-template <bool SPREAD> __device__ static inline uint32_t part_digit(uint64_t key, int64_t idx, int shift, uint64_t ek) {
-  if (SPREAD && key == ek) return (uint32_t)(qr_mix64((uint64_t)idx) >> 56) & (RADIX - 1);
-  return digit_of<SM_MIX>(key, shift);
+template <bool SPREAD>
+__device__ static inline uint32_t part_digit(uint64_t key, int64_t idx, int shift, uint64_t ek, uint32_t dmask) {
+  const uint64_t x = (SPREAD && key == ek) ? qr_mix64((uint64_t)idx) : qr_mix64(key);
+  return (uint32_t)(x >> shift) & dmask;
 }
 
 // ghist layout: [batch][digit][tile]
@@ -51,17 +52,27 @@ template <int MIX, bool SPREAD = false>
 __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const uint64_t *__restrict__ keys, int64_t n,
                                                                  int ntiles, int shift,
                                                                  uint32_t *__restrict__ ghist, uint64_t ek = 0,
-                                                                 int fold = 0) {
+                                                                 int fold = 0, uint32_t dmask = RADIX - 1,
+                                                                 const uint32_t *__restrict__ vals = nullptr) {
   __shared__ uint32_t h[RADIX];
   const int tile = blockIdx.x, batch = blockIdx.y;
   h[threadIdx.x] = 0;
   __syncthreads();
   const uint64_t *k = keys + (size_t)batch * n;
+  const uint32_t *v = vals ? vals + (size_t)batch * n : nullptr;
   const int64_t base = (int64_t)tile * SORT_TILE;
 #pragma unroll
   for (int i = 0; i < SORT_IPT; ++i) {
     const int64_t idx = base + (int64_t)i * SORT_THREADS + threadIdx.x;
-    if (idx < n) atomicAdd(&h[SPREAD ? part_digit<SPREAD>(k[idx], idx, shift, ek) : digit_of<MIX>(k[idx], shift, fold)], 1u);
+    if (idx < n) {
+      const uint64_t key = k[idx];
+      uint32_t d;
+      if (SPREAD)
+        d = part_digit<SPREAD>(key, (key == ek && v) ? (int64_t)v[idx] : idx, shift, ek, dmask);
+      else
+        d = digit_of<MIX>(key, shift, fold);
+      atomicAdd(&h[d], 1u);
+    }
   }
   __syncthreads();
   ghist[((size_t)batch * RADIX + threadIdx.x) * ntiles + tile] = h[threadIdx.x];
@@ -110,7 +121,8 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const uint64
                                                                     int ntiles, int shift,
                                                                     const uint32_t *__restrict__ goff,
                                                                     const uint32_t *__restrict__ rtot,
-                                                                    uint64_t ek = 0, int fold = 0) {
+                                                                    uint64_t ek = 0, int fold = 0,
+                                                                    uint32_t dmask = RADIX - 1) {
   __shared__ uint32_t cnt[SORT_THREADS / WAVE][RADIX];
   __shared__ uint32_t dsum[SORT_THREADS / WAVE];
   const int tile = xcd_tile(blockIdx.x, ntiles), batch = blockIdx.y;
@@ -137,7 +149,8 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const uint64
   for (int k = 0; k < SORT_IPT; ++k) {
     const int64_t idx = wbase + (int64_t)k * WAVE + lane;
     const bool valid = idx < n;
-    const uint32_t d = SPREAD ? part_digit<SPREAD>(key[k], idx, shift, ek) : digit_of<MIX>(key[k], shift, fold);
+    const uint32_t d = SPREAD ? part_digit<SPREAD>(key[k], HAS_VAL ? (int64_t)val[k] : idx, shift, ek, dmask)
+                              : digit_of<MIX>(key[k], shift, fold);
     uint64_t m = __ballot(valid);
 #pragma unroll
     for (int bit = 0; bit < 8; ++bit) {
@@ -260,14 +273,16 @@ QRLSH_EXPORT int qrlsh_sort_u64(uint64_t *keys_a, uint64_t *keys_b, uint32_t *va
 }
 
 // ==========================================================================================
-// Fast bucket path (a2/a3): ONE partition pass + an LDS finish, instead of a full sort.
+// Fast bucket path (a2/a3): a T-bit hash PARTITION + an LDS finish, instead of a full sort.
 //
-//   partition : the first radix pass above on the top 8 bits of mix64(key) (with IOTA ids)
-//               -> per band 256 parts of ~nq/256 records, contiguous in HBM;
-//   finish    : one 1024-thread workgroup per (part, band) stages the part in LDS, links
+//   partition : one or two of the radix passes above on the top T bits of mix64(key)
+//               (T = 8 .. 16, chosen by the host so that a part holds ~2-4 K records)
+//               -> per band 2^T parts, contiguous in HBM, ids ascending inside a part;
+//   bounds    : one thread per (band, part) binary-searches the part's first record;
+//   finish    : one 1024-thread workgroup per (part, band) stages the part's keys in LDS, links
 //               equal keys through an LDS hash table (atomicExch chains) and, per record,
-//               pairs it with every record of the part that has the same FULL key and a
-//               smaller query id -- exactly the (i < j) pairs of that bucket (lsh.py:47-49).
+//               pairs it with every EARLIER record of the part that has the same FULL key --
+//               exactly the (i < j) pairs of that bucket (lsh.py:47-49).
 //
 // Count-then-fill like the general path; a part larger than FIN_CAP records (heavily skewed
 // data) raises the overflow word and the host falls back to the general sort path.
@@ -288,53 +303,56 @@ __device__ static inline uint32_t fin_slot(uint64_t key) {
   return h >> (32 - 12);  // FIN_HT = 4096
 }
 
-// The partition pass is stable and ids enter in ascending order (IOTA), so inside a part
+// starts[band][f] = first position of band `band` whose T-bit part number is >= f (f = 0 .. 2^T)
+__global__ __launch_bounds__(256) void bucket_bounds_kernel(const uint64_t *__restrict__ keys,
+                                                            const uint32_t *__restrict__ ids, int64_t nq, int T,
+                                                            uint64_t ek, uint32_t *__restrict__ starts) {
+  const int nparts = 1 << T;
+  const int f = blockIdx.x * blockDim.x + threadIdx.x, band = blockIdx.y;
+  if (f > nparts) return;
+  const uint64_t *k = keys + (size_t)band * nq;
+  const uint32_t *id = ids + (size_t)band * nq;
+  int64_t lo = 0, hi = nq;  // first t with part(t) >= f
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    const uint64_t key = k[mid];
+    const uint32_t part = part_digit<true>(key, key == ek ? (int64_t)id[mid] : 0, 64 - T, ek, (uint32_t)nparts - 1u);
+    if ((int)part >= f) hi = mid;
+    else lo = mid + 1;
+  }
+  starts[(size_t)band * (nparts + 1) + f] = (uint32_t)lo;
+}
+
+// The partition passes are stable and ids enter in ascending order (IOTA), so inside a part
 // "smaller query id" == "earlier position": the finish never needs the ids to decide, only to
-// write a pair (fill reads them from global memory, L2-hot).  LDS image: keys 48 KB + heads
-// 16 KB + links 12 KB = 76 KB -> two workgroups per CU.
+// write a pair.  LDS image: keys 48 KB + heads 16 KB + links 12 KB = 76 KB -> two workgroups per
+// CU (which also needs <= 64 VGPRs: __launch_bounds__(1024, 8)).
 template <bool FILL>
 __global__ __launch_bounds__(FIN_THREADS, 8) void bucket_finish_kernel(const uint64_t *__restrict__ keys,
-                                                                    const uint32_t *__restrict__ ids, int64_t nq,
-                                                                    const uint32_t *__restrict__ rtot, uint64_t ek,
-                                                                    uint64_t *__restrict__ blk,
-                                                                    uint32_t *__restrict__ overflow,
-                                                                    uint64_t *__restrict__ out) {
+                                                                       const uint32_t *__restrict__ ids, int64_t nq,
+                                                                       const uint32_t *__restrict__ starts,
+                                                                       int nparts, uint64_t ek,
+                                                                       uint64_t *__restrict__ blk,
+                                                                       uint32_t *__restrict__ overflow,
+                                                                       uint64_t *__restrict__ out) {
   __shared__ uint64_t sk[FIN_CAP];
   __shared__ uint32_t head[FIN_HT];
   __shared__ uint16_t nxt[FIN_CAP];
   __shared__ uint64_t wsum[FIN_THREADS / WAVE];
-  __shared__ uint32_t dsum[4];
-  __shared__ uint32_t s_start, s_size;
   const int part = blockIdx.x, band = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid >> 6;
-
-  // part offset = exclusive prefix of the band's 256 part sizes
-  if (tid < RADIX) {
-    const uint32_t tot = rtot[(size_t)band * RADIX + tid];
-    uint32_t inc = tot;
-#pragma unroll
-    for (int k = 1; k < WAVE; k <<= 1) {
-      const uint32_t o = __shfl_up(inc, k, WAVE);
-      if (lane >= k) inc += o;
-    }
-    if (lane == WAVE - 1) dsum[w] = inc;
-    head[tid] = inc - tot;        // temporaries: within-wave exclusive prefix ...
-    head[RADIX + tid] = tot;      // ... and the part size
-  }
-  __syncthreads();
-  if (tid == part) {
-    uint32_t base = head[tid];
-    for (int k = 0; k < (tid >> 6); ++k) base += dsum[k];
-    s_start = base;
-    s_size = head[RADIX + tid];
-  }
-  __syncthreads();
-  const uint32_t start = s_start, m = s_size;
+  const uint32_t start = starts[(size_t)band * (nparts + 1) + part];
+  const uint32_t m = starts[(size_t)band * (nparts + 1) + part + 1] - start;
+  const size_t bslot = (size_t)band * nparts + part;
   if (m > (uint32_t)FIN_CAP) {  // uniform over the workgroup
     if (tid == 0) {
       atomicOr(overflow, 1u);
-      if (!FILL) blk[(size_t)band * RADIX + part] = 0;
+      if (!FILL) blk[bslot] = 0;
     }
+    return;
+  }
+  if (m == 0) {
+    if (!FILL && tid == 0) blk[bslot] = 0;
     return;
   }
   for (int i = tid; i < FIN_HT; i += FIN_THREADS) head[i] = 0xFFFFFFFFu;
@@ -393,7 +411,7 @@ __global__ __launch_bounds__(FIN_THREADS, 8) void bucket_finish_kernel(const uin
     tot += x;
   }
   if (!FILL) {
-    if (tid == 0) blk[(size_t)band * RADIX + part] = tot;
+    if (tid == 0) blk[bslot] = tot;
     return;
   }
   // Emission without a global load inside a chain walk.  The ids came in with the keys
@@ -401,7 +419,7 @@ __global__ __launch_bounds__(FIN_THREADS, 8) void bucket_finish_kernel(const uin
   // all records, so a match position u turns into a query id with one LDS read.  Matches beyond
   // the second of a record (buckets of 4+) are rare: a second walk, done while the keys are
   // still in LDS, writes them straight out with a global id gather.
-  const uint64_t pos0 = blk[(size_t)band * RADIX + part] + base + inc - mine;
+  const uint64_t pos0 = blk[bslot] + base + inc - mine;
   {
     uint64_t pos = pos0;
 #pragma unroll
@@ -440,19 +458,45 @@ __global__ __launch_bounds__(FIN_THREADS, 8) void bucket_finish_kernel(const uin
   }
 }
 
-// workspace: [ghist+rtot of one sort pass][blk: b*256 u64][total u64][overflow u32 (+pad)]
-static size_t bucket_ws_sort_bytes(int64_t nq, int32_t b) { return (qrlsh_sort_workspace_bytes(nq, b) + 15) & ~(size_t)15; }
-
-QRLSH_EXPORT size_t qrlsh_bucket_workspace_bytes(int64_t nq, int32_t b) {
-  if (nq <= 0 || b <= 0) return 64;
-  return bucket_ws_sort_bytes(nq, b) + (size_t)b * RADIX * sizeof(uint64_t) + 16;
+// workspace: [ghist + rtot of one sort pass][starts: b*(2^T+1) u32][blk: b*2^T u64][16 B tail]
+static size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+struct BucketWs {
+  uint32_t *ghist, *rtot, *starts;
+  uint64_t *blk;
+  uint32_t *tail;
+  size_t bytes;
+};
+static BucketWs bucket_ws(void *workspace, int64_t nq, int32_t b, int32_t T) {
+  BucketWs w;
+  const size_t nparts = (size_t)1 << T;
+  const int64_t ntiles = ceil_div64(nq, SORT_TILE);
+  char *p = static_cast<char *>(workspace);
+  size_t off = 0;
+  w.ghist = reinterpret_cast<uint32_t *>(p + off);
+  w.rtot = w.ghist + (size_t)b * RADIX * ntiles;
+  off += align16(qrlsh_sort_workspace_bytes(nq, b));
+  w.starts = reinterpret_cast<uint32_t *>(p + off);
+  off += align16((size_t)b * (nparts + 1) * sizeof(uint32_t));
+  w.blk = reinterpret_cast<uint64_t *>(p + off);
+  off += (size_t)b * nparts * sizeof(uint64_t);
+  w.tail = reinterpret_cast<uint32_t *>(p + off);
+  off += 16;
+  w.bytes = off;
+  return w;
 }
 
-QRLSH_EXPORT int qrlsh_bucket_pairs_count(const uint64_t *keys, uint64_t *part_keys, uint32_t *part_ids, int64_t nq,
-                                          int32_t b, int32_t r, void *workspace, size_t workspace_bytes,
+QRLSH_EXPORT size_t qrlsh_bucket_workspace_bytes(int64_t nq, int32_t b, int32_t part_bits) {
+  if (nq <= 0 || b <= 0 || part_bits < 8 || part_bits > 16) return 64;
+  return bucket_ws(nullptr, nq, b, part_bits).bytes;
+}
+
+QRLSH_EXPORT int qrlsh_bucket_pairs_count(const uint64_t *keys, uint64_t *part_keys, uint32_t *part_ids,
+                                          uint64_t *tmp_keys, uint32_t *tmp_ids, int64_t nq, int32_t b, int32_t r,
+                                          int32_t part_bits, void *workspace, size_t workspace_bytes,
                                           uint64_t *total_overflow_out, void *stream) {
   QR_CHECK_ARG(nq >= 0 && b > 0 && b <= 65535 && r > 0 && r <= 4, "qrlsh_bucket_pairs_count: bad sizes nq=%lld b=%d r=%d",
                (long long)nq, b, r);
+  QR_CHECK_ARG(part_bits >= 8 && part_bits <= 16, "qrlsh_bucket_pairs_count: part_bits=%d not in [8,16]", part_bits);
   QR_CHECK_ARG(nq < (1ll << 32), "qrlsh_bucket_pairs_count: nq too large");
   QR_CHECK_ARG(total_overflow_out && workspace, "qrlsh_bucket_pairs_count: null pointer");
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -462,41 +506,61 @@ QRLSH_EXPORT int qrlsh_bucket_pairs_count(const uint64_t *keys, uint64_t *part_k
   }
   if (nq == 0) return QRLSH_OK;
   QR_CHECK_ARG(keys && part_keys && part_ids, "qrlsh_bucket_pairs_count: null pointer");
-  if (workspace_bytes < qrlsh_bucket_workspace_bytes(nq, b)) {
+  QR_CHECK_ARG(part_bits == 8 || (tmp_keys && tmp_ids), "qrlsh_bucket_pairs_count: part_bits > 8 needs tmp buffers");
+  if (workspace_bytes < qrlsh_bucket_workspace_bytes(nq, b, part_bits)) {
     qrlsh_set_error("qrlsh_bucket_pairs_count: workspace %zu < %zu bytes", workspace_bytes,
-                    qrlsh_bucket_workspace_bytes(nq, b));
+                    qrlsh_bucket_workspace_bytes(nq, b, part_bits));
     return QRLSH_EWORKSPACE;
   }
+  const int T = part_bits, nparts = 1 << T;
   const int ntiles = (int)ceil_div64(nq, SORT_TILE);
-  uint32_t *ghist = static_cast<uint32_t *>(workspace);
-  uint32_t *rtot = ghist + (size_t)b * RADIX * ntiles;
-  uint64_t *blk = reinterpret_cast<uint64_t *>(static_cast<char *>(workspace) + bucket_ws_sort_bytes(nq, b));
+  const BucketWs w = bucket_ws(workspace, nq, b, T);
   const dim3 grid(ntiles, b), block(SORT_THREADS);
-  const int shift = 56;
   const uint64_t ek = qr_empty_key(r);
-  QR_LAUNCH("sort_hist", (sort_hist_kernel<SM_MIX, true>), grid, block, 0, st, keys, nq, ntiles, shift, ghist, ek);
-  QR_LAUNCH("sort_rowscan", sort_rowscan_kernel, dim3(RADIX, b), dim3(256), 0, st, ghist, ntiles, rtot);
-  QR_LAUNCH("sort_scatter_kv", (sort_scatter_kernel<SM_MIX, true, true, true>), grid, block, 0, st, keys,
-            (const uint32_t *)nullptr, part_keys, part_ids, nq, ntiles, shift, ghist, rtot, ek);
-  QR_LAUNCH("bucket_count", (bucket_finish_kernel<false>), dim3(RADIX, b), dim3(FIN_THREADS), 0, st, part_keys, part_ids,
-            nq, rtot, qr_empty_key(r), blk, reinterpret_cast<uint32_t *>(total_overflow_out + 1), (uint64_t *)nullptr);
-  QR_LAUNCH("scan_blocks", scan_u64_kernel, dim3(1), dim3(1024), 0, st, blk, (int64_t)b * RADIX, total_overflow_out);
+  const uint32_t *no_vals = nullptr;
+  if (T == 8) {
+    QR_LAUNCH("sort_hist", (sort_hist_kernel<SM_MIX, true>), grid, block, 0, st, keys, nq, ntiles, 56, w.ghist, ek, 0,
+              (uint32_t)RADIX - 1u, no_vals);
+    QR_LAUNCH("sort_rowscan", sort_rowscan_kernel, dim3(RADIX, b), dim3(256), 0, st, w.ghist, ntiles, w.rtot);
+    QR_LAUNCH("sort_scatter_kv", (sort_scatter_kernel<SM_MIX, true, true, true>), grid, block, 0, st, keys, no_vals,
+              part_keys, part_ids, nq, ntiles, 56, w.ghist, w.rtot, ek, 0, (uint32_t)RADIX - 1u);
+  } else {
+    // LSD over the T-bit part number: low T-8 bits first, then the top 8
+    const uint32_t lowmask = (1u << (T - 8)) - 1u;
+    QR_LAUNCH("sort_hist", (sort_hist_kernel<SM_MIX, true>), grid, block, 0, st, keys, nq, ntiles, 64 - T, w.ghist, ek, 0,
+              lowmask, no_vals);
+    QR_LAUNCH("sort_rowscan", sort_rowscan_kernel, dim3(RADIX, b), dim3(256), 0, st, w.ghist, ntiles, w.rtot);
+    QR_LAUNCH("sort_scatter_kv", (sort_scatter_kernel<SM_MIX, true, true, true>), grid, block, 0, st, keys, no_vals,
+              tmp_keys, tmp_ids, nq, ntiles, 64 - T, w.ghist, w.rtot, ek, 0, lowmask);
+    QR_LAUNCH("sort_hist", (sort_hist_kernel<SM_MIX, true>), grid, block, 0, st, (const uint64_t *)tmp_keys, nq, ntiles,
+              56, w.ghist, ek, 0, (uint32_t)RADIX - 1u, (const uint32_t *)tmp_ids);
+    QR_LAUNCH("sort_rowscan", sort_rowscan_kernel, dim3(RADIX, b), dim3(256), 0, st, w.ghist, ntiles, w.rtot);
+    QR_LAUNCH("sort_scatter_kv", (sort_scatter_kernel<SM_MIX, true, false, true>), grid, block, 0, st,
+              (const uint64_t *)tmp_keys, (const uint32_t *)tmp_ids, part_keys, part_ids, nq, ntiles, 56, w.ghist,
+              w.rtot, ek, 0, (uint32_t)RADIX - 1u);
+  }
+  QR_LAUNCH("bucket_bounds", bucket_bounds_kernel, dim3((nparts + 1 + 255) / 256, b), dim3(256), 0, st,
+            (const uint64_t *)part_keys, (const uint32_t *)part_ids, nq, T, ek, w.starts);
+  QR_LAUNCH("bucket_count", (bucket_finish_kernel<false>), dim3(nparts, b), dim3(FIN_THREADS), 0, st,
+            (const uint64_t *)part_keys, (const uint32_t *)part_ids, nq, (const uint32_t *)w.starts, nparts, ek, w.blk,
+            reinterpret_cast<uint32_t *>(total_overflow_out + 1), (uint64_t *)nullptr);
+  QR_LAUNCH("scan_blocks", scan_u64_kernel, dim3(1), dim3(1024), 0, st, w.blk, (int64_t)b * nparts, total_overflow_out);
   QR_LAUNCH_CHECK("qrlsh_bucket_pairs_count");
   return QRLSH_OK;
 }
 
 QRLSH_EXPORT int qrlsh_bucket_pairs_fill(const uint64_t *part_keys, const uint32_t *part_ids, int64_t nq, int32_t b,
-                                         int32_t r, void *workspace, uint64_t *pairs_out, void *stream) {
-  QR_CHECK_ARG(nq >= 0 && b > 0 && r > 0 && r <= 4, "qrlsh_bucket_pairs_fill: bad sizes");
+                                         int32_t r, int32_t part_bits, void *workspace, uint64_t *pairs_out,
+                                         void *stream) {
+  QR_CHECK_ARG(nq >= 0 && b > 0 && r > 0 && r <= 4 && part_bits >= 8 && part_bits <= 16,
+               "qrlsh_bucket_pairs_fill: bad sizes");
   if (nq == 0) return QRLSH_OK;
   QR_CHECK_ARG(part_keys && part_ids && workspace && pairs_out, "qrlsh_bucket_pairs_fill: null pointer");
-  const int ntiles = (int)ceil_div64(nq, SORT_TILE);
-  uint32_t *ghist = static_cast<uint32_t *>(workspace);
-  uint32_t *rtot = ghist + (size_t)b * RADIX * ntiles;
-  uint64_t *blk = reinterpret_cast<uint64_t *>(static_cast<char *>(workspace) + bucket_ws_sort_bytes(nq, b));
-  uint32_t *ovf = reinterpret_cast<uint32_t *>(blk + (size_t)b * RADIX);  // scratch word (result ignored here)
-  QR_LAUNCH("bucket_fill", (bucket_finish_kernel<true>), dim3(RADIX, b), dim3(FIN_THREADS), 0,
-            static_cast<hipStream_t>(stream), part_keys, part_ids, nq, rtot, qr_empty_key(r), blk, ovf, pairs_out);
+  const int nparts = 1 << part_bits;
+  const BucketWs w = bucket_ws(workspace, nq, b, part_bits);
+  QR_LAUNCH("bucket_fill", (bucket_finish_kernel<true>), dim3(nparts, b), dim3(FIN_THREADS), 0,
+            static_cast<hipStream_t>(stream), part_keys, part_ids, nq, (const uint32_t *)w.starts, nparts,
+            qr_empty_key(r), w.blk, w.tail, pairs_out);
   QR_LAUNCH_CHECK("qrlsh_bucket_pairs_fill");
   return QRLSH_OK;
 }

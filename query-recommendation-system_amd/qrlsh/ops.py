@@ -253,25 +253,40 @@ def sort_pairs(pairs, nq):
     return p
 
 
-def emit_pairs_fast(keys, r):
+def part_bits_for(n):
+    """T = bits of the hash partition of the fast bucket path: parts of <= ~4400 records on
+    average (the LDS image holds 6144), at least 8, at most 16."""
+    t = 8
+    while t < 16 and n > 4400 * (1 << t):
+        t += 1
+    return t
+
+
+def emit_pairs_fast(keys, r, part_bits=None):
     """emit_pairs for unsorted band-major keys through the partition + LDS-finish path.
     Returns the pairs tensor, or None when a part overflowed the LDS image (skewed data)."""
     lib = _lib.load()
     _need(keys, torch.int64, "keys", 2)
     b, nq = keys.shape
     dev = keys.device
+    T = part_bits if part_bits is not None else part_bits_for(nq)
+    if nq > 6144 * (1 << T):
+        return None  # cannot fit even with the finest partition
     pk = torch.empty_like(keys)
     pid = torch.empty((b, nq), dtype=torch.int32, device=dev)
-    ws = _ws(lib.qrlsh_bucket_workspace_bytes(nq, b), dev)
+    tk = torch.empty_like(keys) if T > 8 else None
+    tid = torch.empty((b, nq), dtype=torch.int32, device=dev) if T > 8 else None
+    ws = _ws(lib.qrlsh_bucket_workspace_bytes(nq, b, T), dev)
     tot = torch.zeros(2, dtype=torch.int64, device=dev)
-    _lib.check(lib.qrlsh_bucket_pairs_count(_ptr(keys), _ptr(pk), _ptr(pid), nq, b, r, _ptr(ws), ws.numel(), _ptr(tot),
-                                            _stream()))
+    _lib.check(lib.qrlsh_bucket_pairs_count(_ptr(keys), _ptr(pk), _ptr(pid), _ptr(tk), _ptr(tid), nq, b, r, T,
+                                            _ptr(ws), ws.numel(), _ptr(tot), _stream()))
     n, overflow = tot.tolist()
     if overflow:
         return None
+    del tk, tid
     pairs = torch.empty((n,), dtype=torch.int64, device=dev)
     if n:
-        _lib.check(lib.qrlsh_bucket_pairs_fill(_ptr(pk), _ptr(pid), nq, b, r, _ptr(ws), _ptr(pairs), _stream()))
+        _lib.check(lib.qrlsh_bucket_pairs_fill(_ptr(pk), _ptr(pid), nq, b, r, T, _ptr(ws), _ptr(pairs), _stream()))
     return pairs
 
 

@@ -382,11 +382,12 @@ def test_fast_bucket_path_equals_general_path():
             with_cap = ops.emit_pairs_fast(dev(k.view(np.int64)), 4)
             assert with_cap is None                              # 300000/40 per key > LDS image -> overflow
             continue
-        fast = ops.emit_pairs_fast(dev(k.view(np.int64)), 4)
         sk, sid = ops.bucket_sort(dev(k.view(np.int64)))
-        gen = ops.emit_pairs(sk, sid, 4)
-        assert fast is not None and fast.numel() == gen.numel()
-        assert np.array_equal(np.sort(u64(fast)), np.sort(u64(gen)))
+        gen = np.sort(u64(ops.emit_pairs(sk, sid, 4)))
+        for T in (None, 9, 12, 16):                               # one- and two-pass partitions
+            fast = ops.emit_pairs_fast(dev(k.view(np.int64)), 4, part_bits=T)
+            assert fast is not None and fast.numel() == gen.size
+            assert np.array_equal(np.sort(u64(fast)), gen)
 
 
 def test_overflowing_part_falls_back_to_general_path():
