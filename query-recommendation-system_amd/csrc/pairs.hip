@@ -142,18 +142,32 @@ template <int PRED> __device__ static inline bool keep_at(const uint64_t *__rest
   return t < K || (a[t - K] >> sh) != (a[t] >> sh);
 }
 
+// Tile = CMP_TILE words; wave w owns the contiguous slice [w*512, (w+1)*512) and sweeps it 64
+// words at a time, so loads are coalesced and the kept words of a sweep take consecutive output
+// positions (ballot + popcount): stores are coalesced too.
+constexpr int CMP_WAVES = CMP_THREADS / WAVE;
+constexpr int CMP_PER_WAVE = CMP_TILE / CMP_WAVES;
+
 template <int PRED>
 __global__ __launch_bounds__(CMP_THREADS) void compact_count_kernel(const uint64_t *__restrict__ a, int64_t n, int K,
                                                                     int sh, uint64_t *__restrict__ blk) {
-  __shared__ uint64_t sm[4];
-  const int64_t t0 = (int64_t)blockIdx.x * CMP_TILE + (int64_t)threadIdx.x * CMP_IPT;
-  uint64_t c = 0;
+  __shared__ uint32_t wtot[CMP_WAVES];
+  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x >> 6;
+  const int64_t base = (int64_t)blockIdx.x * CMP_TILE + (int64_t)w * CMP_PER_WAVE;
+  uint32_t c = 0;
 #pragma unroll
-  for (int i = 0; i < CMP_IPT; ++i)
-    if (t0 + i < n) c += keep_at<PRED>(a, t0 + i, K, sh) ? 1 : 0;
-  uint64_t total;
-  (void)block_excl_scan_u64_256(c, sm, &total);
-  if (threadIdx.x == 0) blk[blockIdx.x] = total;
+  for (int i = 0; i < CMP_PER_WAVE / WAVE; ++i) {
+    const int64_t t = base + i * WAVE + lane;
+    const bool keep = t < n && keep_at<PRED>(a, t, K, sh);
+    c += (uint32_t)__popcll(__ballot(keep));
+  }
+  if (lane == 0) wtot[w] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint64_t tot = 0;
+    for (int i = 0; i < CMP_WAVES; ++i) tot += wtot[i];
+    blk[blockIdx.x] = tot;
+  }
 }
 
 template <int PRED>
@@ -164,30 +178,39 @@ __global__ __launch_bounds__(CMP_THREADS) void compact_fill_kernel(const uint64_
                                                                    int32_t *__restrict__ src_out,
                                                                    int32_t *__restrict__ dst_out,
                                                                    int32_t *__restrict__ milli_out) {
-  __shared__ uint64_t sm[4];
-  const int64_t t0 = (int64_t)blockIdx.x * CMP_TILE + (int64_t)threadIdx.x * CMP_IPT;
-  bool keep[CMP_IPT];
-  uint64_t c = 0;
+  __shared__ uint32_t wtot[CMP_WAVES];
+  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x >> 6;
+  const int64_t base = (int64_t)blockIdx.x * CMP_TILE + (int64_t)w * CMP_PER_WAVE;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  uint64_t v[CMP_PER_WAVE / WAVE];
+  uint64_t masks[CMP_PER_WAVE / WAVE];
+  uint32_t c = 0;
 #pragma unroll
-  for (int i = 0; i < CMP_IPT; ++i) {
-    keep[i] = (t0 + i < n) && keep_at<PRED>(a, t0 + i, K, sh);
-    c += keep[i] ? 1 : 0;
+  for (int i = 0; i < CMP_PER_WAVE / WAVE; ++i) {
+    const int64_t t = base + i * WAVE + lane;
+    v[i] = t < n ? a[t] : 0;
+    const bool keep = t < n && keep_at<PRED>(a, t, K, sh);
+    masks[i] = __ballot(keep);
+    c += (uint32_t)__popcll(masks[i]);
   }
-  uint64_t total;
-  uint64_t pos = blk[blockIdx.x] + block_excl_scan_u64_256(c, sm, &total);
+  if (lane == 0) wtot[w] = c;
+  __syncthreads();
+  uint64_t pos = blk[blockIdx.x];
+  for (int i = 0; i < w; ++i) pos += wtot[i];
+  const uint64_t idm = (1ull << id_bits) - 1ull;
 #pragma unroll
-  for (int i = 0; i < CMP_IPT; ++i) {
-    if (!keep[i]) continue;
-    const uint64_t v = a[t0 + i];
-    if (PRED == PRED_UNIQUE) {
-      out_u64[pos] = v;
-    } else {
-      const uint64_t idm = (1ull << id_bits) - 1ull;
-      src_out[pos] = (int32_t)(v >> sh);
-      dst_out[pos] = (int32_t)(v & idm);
-      milli_out[pos] = 1000 - (int32_t)((v >> id_bits) & 0x7FFull);
+  for (int i = 0; i < CMP_PER_WAVE / WAVE; ++i) {
+    if ((masks[i] >> lane) & 1ull) {
+      const uint64_t p = pos + (uint64_t)__popcll(masks[i] & lt_mask);
+      if (PRED == PRED_UNIQUE) {
+        out_u64[p] = v[i];
+      } else {
+        src_out[p] = (int32_t)(v[i] >> sh);
+        dst_out[p] = (int32_t)(v[i] & idm);
+        milli_out[p] = 1000 - (int32_t)((v[i] >> id_bits) & 0x7FFull);
+      }
     }
-    ++pos;
+    pos += (uint64_t)__popcll(masks[i]);
   }
 }
 
