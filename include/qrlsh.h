@@ -163,6 +163,22 @@ int qrlsh_topk_fill(const uint64_t *sorted_edges, int64_t n_edges, int32_t K, in
                     const void *workspace, int32_t *src_out, int32_t *dst_out, int32_t *milli_out,
                     void *stream);
 
+/* ---- N2: answer sets (the producer of the hot path's input) ---------------------------------
+ * Replaces Recommender.compute_shingles, recommender.py:68-103, for queries that are
+ * conjunctions of attribute=value: bitmaps[row][words_per_row] holds one bit per table row for
+ * every (feature, value) of the table (bit i of word w = table row 32*w + i; D = table rows);
+ * qrows[q][f] names the bitmap row of query q's value for feature f, -1 = unconstrained (a value
+ * absent from the table points at an all-zero row).  count: sizes_out[q] = |A(q)|;
+ * fill: rows_out[offsets[q] ..) = the matching table rows, ascending (offsets = exclusive scan
+ * of the sizes) -- the CSR qrlsh_minhash consumes.  nfeat <= 64.
+ */
+int qrlsh_answer_sets_count(const uint32_t *bitmaps, int64_t words_per_row, int64_t D,
+                            const int32_t *qrows, int64_t nq, int32_t nfeat, int32_t *sizes_out,
+                            void *stream);
+int qrlsh_answer_sets_fill(const uint32_t *bitmaps, int64_t words_per_row, int64_t D,
+                           const int32_t *qrows, int64_t nq, int32_t nfeat, const int64_t *offsets,
+                           int32_t *rows_out, void *stream);
+
 /* ---- synthetic answer sets (bench / test input) ---------------
  * Bit-identical twin of oracle/qr_oracle.c:qro_synth_*: a pure function of (seed, q).
  * sizes: sizes_out[i] = |A(q0 + i)|; fill: rows at offsets[i] (offsets = exclusive scan).

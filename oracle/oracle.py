@@ -195,6 +195,25 @@ def sims_to_dict(src, dst, val):
     return out
 
 
+def answer_sets(columns, queries):
+    """recommender.py:83-95: per query, AND of (column == value) over its constrained features
+    ("" = unconstrained), indices of the surviving rows.  columns: list of 1-D str arrays;
+    queries: (nq, nfeat) str array.  -> CSR (offsets int64, rows int32)."""
+    columns = [np.asarray(c) for c in columns]
+    D = len(columns[0])
+    sets = []
+    for q in range(len(queries)):
+        cond = np.ones(D, dtype=bool)
+        for ft in range(len(columns)):
+            if queries[q][ft] != "":
+                cond &= (columns[ft] == queries[q][ft])
+        sets.append(np.flatnonzero(cond).astype(np.int32))
+    offsets = np.zeros(len(sets) + 1, dtype=np.int64)
+    np.cumsum([len(x) for x in sets], out=offsets[1:])
+    rows = np.concatenate(sets).astype(np.int32) if sets else np.zeros(0, np.int32)
+    return offsets, rows
+
+
 # ---------------------------------------------------------------------------
 # synthetic answer sets (bench / test input; not part of the reference)
 # ---------------------------------------------------------------------------

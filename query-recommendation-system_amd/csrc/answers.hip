@@ -1,0 +1,101 @@
+// answers.hip -- N2: answer sets of conjunctive attribute=value queries (the producer of the hot
+// path's input).
+//
+// Reference: Recommender.compute_shingles, recommender.py:68-103 -- per query a pandas boolean
+// mask per constrained feature (dataset[feature] == value), AND-ed (:87-89), and the indices
+// of the surviving rows (:91).  Here every (feature, value) of the table has one bitmap over
+// the D table rows (the query x item incidence structure, one bit per cell); a query is the AND
+// of at most nfeat bitmap rows.  One wave per query sweeps the D/32 words 64 at a time
+// (coalesced 256-B reads per bitmap row, L2-resident), popcounts for the size pass, and in the
+// fill pass turns set bits into ascending row ids with a wave prefix sum -- the CSR
+// (offsets, rows) that qrlsh_minhash consumes, built without leaving the device.
+#include "common.h"
+
+// qrows[q][f] : bitmap row of query q's value for feature f, or -1 when the feature is
+//               unconstrained ("" in the reference, :86); a value absent from the table must
+//               point at an all-zero bitmap row.
+template <bool FILL>
+__global__ __launch_bounds__(256) void answer_sets_kernel(const uint32_t *__restrict__ bitmaps, int64_t wpr,
+                                                          int64_t D, const int32_t *__restrict__ qrows, int64_t nq,
+                                                          int nfeat,
+                                                          int32_t *__restrict__ sizes,
+                                                          const int64_t *__restrict__ offsets,
+                                                          int32_t *__restrict__ rows) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (q >= nq) return;  // wave-uniform
+  // the (at most 64) bitmap rows of this query, one per lane
+  const int32_t myrow = lane < nfeat ? qrows[q * nfeat + lane] : -1;
+  int64_t out = FILL ? offsets[q] : 0;
+  uint32_t total = 0;
+  for (int64_t w0 = 0; w0 < wpr; w0 += WAVE) {
+    const int64_t w = w0 + lane;
+    uint32_t word = 0u;  // rows >= D never match (an unconstrained query keeps exactly the D table rows)
+    if (w < wpr && w * 32 < D) word = (D - w * 32 >= 32) ? 0xFFFFFFFFu : ((1u << (D - w * 32)) - 1u);
+    for (int f = 0; f < nfeat; ++f) {
+      const int32_t r = __shfl(myrow, f, WAVE);
+      if (r >= 0 && w < wpr) word &= bitmaps[(size_t)r * wpr + w];
+    }
+    const uint32_t pc = (uint32_t)__popc(word);
+    if (!FILL) {
+      total += pc;
+    } else {
+      // exclusive prefix of the lanes' popcounts: where this lane's rows start
+      uint32_t inc = pc;
+#pragma unroll
+      for (int d = 1; d < WAVE; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d, WAVE);
+        if (lane >= d) inc += o;
+      }
+      int64_t p = out + (inc - pc);
+      while (word) {
+        const int bit = __ffs(word) - 1;
+        rows[p++] = (int32_t)(w * 32 + bit);
+        word &= word - 1;
+      }
+      out += __shfl(inc, WAVE - 1, WAVE);
+    }
+  }
+  if (!FILL) {
+#pragma unroll
+    for (int m = 1; m < WAVE; m <<= 1) total += __shfl_xor(total, m, WAVE);
+    if (lane == 0) sizes[q] = (int32_t)total;
+  }
+}
+
+static int answers_check(const uint32_t *bitmaps, int64_t wpr, int64_t D, const int32_t *qrows, int64_t nq,
+                         int32_t nfeat, const char *name) {
+  QR_CHECK_ARG(nq >= 0 && wpr > 0 && nfeat > 0 && nfeat <= WAVE && D > 0 && D <= wpr * 32,
+               "%s: bad sizes nq=%lld words_per_row=%lld D=%lld nfeat=%d", name, (long long)nq, (long long)wpr,
+               (long long)D, nfeat);
+  QR_CHECK_ARG(nq == 0 || (bitmaps && qrows), "%s: null pointer", name);
+  return QRLSH_OK;
+}
+
+QRLSH_EXPORT int qrlsh_answer_sets_count(const uint32_t *bitmaps, int64_t words_per_row, int64_t D,
+                                         const int32_t *qrows, int64_t nq, int32_t nfeat, int32_t *sizes_out,
+                                         void *stream) {
+  const int rc = answers_check(bitmaps, words_per_row, D, qrows, nq, nfeat, "qrlsh_answer_sets_count");
+  if (rc != QRLSH_OK) return rc;
+  if (nq == 0) return QRLSH_OK;
+  QR_CHECK_ARG(sizes_out, "qrlsh_answer_sets_count: null output");
+  QR_LAUNCH("answers_count", (answer_sets_kernel<false>), dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 0,
+            static_cast<hipStream_t>(stream), bitmaps, words_per_row, D, qrows, nq, nfeat, sizes_out,
+            (const int64_t *)nullptr, (int32_t *)nullptr);
+  QR_LAUNCH_CHECK("qrlsh_answer_sets_count");
+  return QRLSH_OK;
+}
+
+QRLSH_EXPORT int qrlsh_answer_sets_fill(const uint32_t *bitmaps, int64_t words_per_row, int64_t D,
+                                        const int32_t *qrows, int64_t nq, int32_t nfeat, const int64_t *offsets,
+                                        int32_t *rows_out, void *stream) {
+  const int rc = answers_check(bitmaps, words_per_row, D, qrows, nq, nfeat, "qrlsh_answer_sets_fill");
+  if (rc != QRLSH_OK) return rc;
+  if (nq == 0) return QRLSH_OK;
+  QR_CHECK_ARG(offsets, "qrlsh_answer_sets_fill: null offsets");
+  QR_LAUNCH("answers_fill", (answer_sets_kernel<true>), dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 0,
+            static_cast<hipStream_t>(stream), bitmaps, words_per_row, D, qrows, nq, nfeat, (int32_t *)nullptr, offsets,
+            rows_out);
+  QR_LAUNCH_CHECK("qrlsh_answer_sets_fill");
+  return QRLSH_OK;
+}

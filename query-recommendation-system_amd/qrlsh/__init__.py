@@ -32,5 +32,6 @@ from .pipeline import (  # noqa: F401
     HotPathResult,
 )
 from .synth import synth_csr, poisson_cdf_u32  # noqa: F401
+from .answers import build_answer_index, encode_queries, answer_sets, AnswerIndex  # noqa: F401
 
 __all__ = [n for n in dir() if not n.startswith("_")]

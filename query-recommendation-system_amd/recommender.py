@@ -12,8 +12,9 @@ np.random.seed(s) the signatures are bit-identical to the reference's.  Tie orde
 query's top-K list is defined here (value descending, then neighbour id ascending); the
 reference's is arbitrary.
 
+Answer sets (compute_shingles) are built on the device too (qrlsh.answers).
 User similarity, the prediction loop, CSV ingest and the interactive prompt are outside this
-round's scope (SURVEY.md section 8f, rows N1-N4).
+round's scope (SURVEY.md section 8f, rows N1, N3, N4).
 """
 import math
 import time
@@ -58,29 +59,26 @@ class Recommender:
         r = ratings.drop(columns=["user"]) if hasattr(ratings, "drop") and "user" in getattr(ratings, "columns", []) else ratings
         self.ratings = np.nan_to_num(to_np(r).astype(float), nan=0.0)
 
-    # ---- producer of the hot path's input (row N2: still host-side) -------------
+    # ---- producer of the hot path's input (row N2: answer sets on the device) -----
+    def answer_sets_device(self):
+        """CSR answer sets on the device: (offsets int64 [nq+1], rows int32 [nnz]); the table is
+        dictionary-encoded into per-(feature, value) bitmaps once and cached."""
+        from qrlsh import answers
+        idx = getattr(self, "_answer_index", None)
+        if idx is None or getattr(self, "_answer_index_key", None) != id(self.dataset):
+            cols = [self.dataset[f].to_numpy() for f in self.datasetFeatures]
+            idx = answers.build_answer_index(cols, self.device)
+            self._answer_index, self._answer_index_key = idx, id(self.dataset)
+        qrows = answers.encode_queries(idx, self.queries)
+        return answers.answer_sets(idx, qrows)
+
     def answer_sets(self):
-        """CSR form of compute_shingles: (offsets int64 [nq+1], rows int32 [nnz]), rows ascending."""
-        nq = self.queriesIDs.size
-        cols = [self.dataset[f].to_numpy() for f in self.datasetFeatures]
-        sets = []
-        for q in range(nq):
-            cond = None
-            for ft in range(len(self.datasetFeatures)):
-                v = self.queries[q][ft]
-                if v != "":
-                    m = cols[ft] == v
-                    cond = m if cond is None else (cond & m)
-            if cond is None:
-                idx = np.arange(self.dataset.shape[0])
-            else:
-                idx = np.flatnonzero(cond)
-            self.tupleCount[q] = len(idx)
-            sets.append(idx.astype(np.int32))
-        offsets = np.zeros(nq + 1, dtype=np.int64)
-        np.cumsum([len(s) for s in sets], out=offsets[1:])
-        rows = np.concatenate(sets) if sets else np.zeros(0, np.int32)
-        return offsets, rows.astype(np.int32)
+        """host copy of answer_sets_device(): (offsets int64 [nq+1], rows int32 [nnz])"""
+        off, rows = self.answer_sets_device()
+        off, rows = off.cpu().numpy(), rows.cpu().numpy()
+        for q, n in enumerate(np.diff(off)):
+            self.tupleCount[q] = int(n)      # recommender.py:93
+        return off, rows
 
     def compute_shingles(self):
         """recommender.py:68-103: inverted index row -> [queries containing it]."""
@@ -97,13 +95,13 @@ class Recommender:
 
     # ---- hot path ------------------------------------------------------------------
     def _device_inputs(self):
-        offsets, rows = self.answer_sets()
+        offsets, rows = self.answer_sets_device()
         drows = self.dataset.shape[0]
         self._log("\nPermutations: {}".format(PERM))
         # PERM consecutive draws from the global legacy RNG, exactly as recommender.py:120
         perms = ops.legacy_permutations(PERM, drows, rng=np.random)
         table = ops.perm_table(perms, self.device)
-        return (torch.from_numpy(offsets).to(self.device), torch.from_numpy(rows).to(self.device), table)
+        return offsets, rows, table
 
     def compute_signatures(self):
         """(nq, PERM) int64 signature matrix (recommender.py:105-143)."""

@@ -402,3 +402,32 @@ def test_overflowing_part_falls_back_to_general_path():
     st2 = {}
     ops.candidate_pairs(ops.band_keys(dev(sig[:900]), 1), 4, st2)
     assert st2["bucket_path"] == "partition+lds"
+
+
+# ---------------------------------------------------------------------------- N2: answer sets
+def test_device_answer_sets_match_reference_and_oracle():
+    from qrlsh import answers
+    from test_oracle_golden import _cfg1_table_and_queries
+    g = load("cfg1_hotpath")
+    cols, queries = _cfg1_table_and_queries()
+    idx = answers.build_answer_index(cols, DEV)
+    off, rows = answers.answer_sets(idx, answers.encode_queries(idx, queries))
+    assert np.array_equal(off.cpu().numpy(), g["offsets"]) and np.array_equal(rows.cpu().numpy(), g["rows"])
+    # random tables: D not a multiple of 32, > 64 words per row, absent values, unconstrained queries
+    rng = np.random.default_rng(9)
+    for (D, nfeat, card, nq) in [(1, 1, 1, 3), (33, 2, 3, 40), (1000, 5, 7, 300), (70001, 3, 50, 500), (5000, 6, 2, 200)]:
+        cols = [rng.integers(0, card, size=D).astype(str) for _ in range(nfeat)]
+        q = np.full((nq, nfeat), "", dtype=object)
+        for i in range(nq):
+            for f in range(nfeat):
+                u = rng.random()
+                if u < 0.5:
+                    q[i, f] = str(rng.integers(0, card))
+                elif u < 0.55:
+                    q[i, f] = "no-such-value"
+        q[0, :] = ""                                   # fully unconstrained -> every table row
+        idx = answers.build_answer_index(cols, DEV)
+        off, rows = answers.answer_sets(idx, answers.encode_queries(idx, q))
+        roff, rrows = O.answer_sets(cols, q)
+        assert np.array_equal(off.cpu().numpy(), roff) and np.array_equal(rows.cpu().numpy(), rrows)
+        assert int(off[1]) == D

@@ -104,3 +104,31 @@ def test_synth_generator_is_a_pure_function_of_index():
     for q in (0, 17, 3999):
         s = rows[off[q]:off[q + 1]]
         assert np.all(np.diff(s) > 0) and s.min() >= 0 and s.max() < 32768
+
+
+def _cfg1_table_and_queries():
+    import os
+    import pandas as pd
+    from helpers import GOLDEN
+    gdir = os.path.join(GOLDEN, "cfg1")
+    dataset = pd.read_csv(os.path.join(gdir, "dataset.csv"), dtype=str)
+    feats = list(dataset.columns)[1:]
+    qrows = []
+    with open(os.path.join(gdir, "queries.csv")) as fh:
+        for line in fh:
+            vals = line.rstrip("\n").split(",")
+            el = ["" for _ in feats]
+            for v in vals[1:]:
+                a = v.split("=")
+                el[feats.index(a[0])] = a[1]
+            qrows.append(el)
+    return [dataset[f].to_numpy() for f in feats], np.array(qrows, dtype=object)
+
+
+def test_answer_sets_match_reference_compute_shingles():
+    """N2: the restated compute_shingles against the CSR derived from the reference's own
+    compute_shingles() output on the generator-default CSVs (tools/make_golden.py)."""
+    g = load("cfg1_hotpath")
+    cols, queries = _cfg1_table_and_queries()
+    off, rows = O.answer_sets(cols, queries)
+    assert np.array_equal(off, g["offsets"]) and np.array_equal(rows, g["rows"])
