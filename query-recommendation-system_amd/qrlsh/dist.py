@@ -4,14 +4,15 @@ over xGMI on the GPU box, "gloo" in the CPU tests).
 Rank g owns the contiguous query range [g*nql, (g+1)*nql) and bands {k : k // ceil(b/W) == g}.
 
   1. MinHash + band keys + norms on the local shard (no communication).
-  2. signature rows and norms start an ASYNC all-gather (they are only needed for scoring,
-     so the transfer hides behind steps 3-6).
-  3. bucket-id exchange so that cross-shard candidates are found.  Two modes with identical
+  2. bucket-id exchange so that cross-shard candidates are found.  Two modes with identical
      results:
        "all_to_all" (default): band-partitioned -- a rank receives only the bands it owns,
                      b/W * nq_total * 8 bytes instead of b * nq_total * 8;
        "all_gather": every rank receives every band key (the exchange BASELINE.json's
                      north_star names), then keeps its bands.
+  3. signature rows (compact uint16 when lossless) and norms start an ASYNC all-gather on a
+     second communicator: they are only needed for scoring, so the transfer runs beside
+     steps 4-5 instead of ahead of the short exchanges.
   4. per owned band: bucket sort + pair emission over ALL queries; local sort + unique.
   5. pairs go to the owner of their smaller query id (variable-size all-to-all); the owner
      sorts + uniques what it received -> its share of the global candidate set.
@@ -54,6 +55,23 @@ class HipBackend:
 
     def topk(self, edges, K, id_bits):
         return ops.topk_edges(edges, K, id_bits)
+
+
+_BG_GROUPS = {}
+
+
+def background_group(group=None):
+    """A second communicator over the same ranks for the long signature all-gather, so that it
+    runs beside the short exchanges instead of ahead of them (collectives of ONE communicator
+    execute in issue order).  Created collectively on first use, then cached."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return group
+    key = id(group) if group is not None else 0
+    if key not in _BG_GROUPS:
+        ranks = dist.get_process_group_ranks(group) if group is not None else list(range(world))
+        _BG_GROUPS[key] = dist.new_group(ranks=ranks)
+    return _BG_GROUPS[key]
 
 
 def band_owner_ranges(b, world):
@@ -143,13 +161,7 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
     # 1. local signatures
     sig, norm2, keys = be.minhash(offsets, rows, table, b)
 
-    # 2. async gather of the signature rows + norms (consumed in step 6)
-    sig_all = torch.empty((nq_total, P), dtype=sig.dtype, device=dev)
-    norm_all = torch.empty((nq_total,), dtype=torch.int64, device=dev)
-    h_sig = _all_gather(sig_all, sig, group, async_op=True)
-    h_nrm = _all_gather(norm_all, norm2, group, async_op=True)
-
-    # 3. bucket-id exchange
+    # 2. bucket-id exchange (short, needed at once: issued before the long gather)
     ranges = band_owner_ranges(b, world)
     lo, hi = ranges[rank]
     nb = hi - lo
@@ -167,6 +179,14 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
     else:
         raise ValueError("exchange must be 'all_to_all' or 'all_gather'")
     del keys
+
+    # 3. async gather of the signature rows + norms on the background communicator (consumed in
+    #    step 6; overlaps steps 4-5)
+    bg = background_group(group)
+    sig_all = torch.empty((nq_total, P), dtype=sig.dtype, device=dev)
+    norm_all = torch.empty((nq_total,), dtype=torch.int64, device=dev)
+    h_sig = _all_gather(sig_all, sig, bg, async_op=True)
+    h_nrm = _all_gather(norm_all, norm2, bg, async_op=True)
 
     # 4. candidates of the owned bands over all queries
     pair_bits = [(0, ib), (32, 32 + ib)]
