@@ -431,3 +431,35 @@ def test_device_answer_sets_match_reference_and_oracle():
         roff, rrows = O.answer_sets(cols, q)
         assert np.array_equal(off.cpu().numpy(), roff) and np.array_equal(rows.cpu().numpy(), rrows)
         assert int(off[1]) == D
+
+
+# ---------------------------------------------------------------------------- degenerate inputs
+def test_pipeline_degenerate_inputs():
+    P, D, b = 16, 50, 4
+    perms = ops.legacy_permutations(P, D, seed=1)
+    table = ops.perm_table(perms, DEV)
+
+    def run(sets, K=5):
+        off = np.zeros(len(sets) + 1, np.int64)
+        off[1:] = np.cumsum([len(s) for s in sets])
+        rows = (np.concatenate(sets) if len(sets) and off[-1] else np.zeros(0)).astype(np.int32)
+        res = pipeline.query_similarities(dev(off), dev(rows), table, b, K)
+        torch.cuda.synchronize()
+        ref = O.query_similarities(off, rows, D, P, b, K, 1)
+        assert np.array_equal(res.sig_int32().cpu().numpy(), ref["sig"])
+        assert np.array_equal(u64(res.pairs), ref["pairs"])
+        assert np.array_equal(res.milli.cpu().numpy(), ref["milli"])
+        assert np.array_equal(res.src.cpu().numpy(), ref["src"]) and np.array_equal(res.dst.cpu().numpy(), ref["dst"])
+        assert np.array_equal(res.val.cpu().numpy(), ref["val"])
+        return res
+
+    e = np.zeros(0, np.int32)
+    assert run([]).pairs.numel() == 0                                   # no queries at all
+    assert run([np.array([3, 7], np.int32)]).pairs.numel() == 0         # one query
+    assert run([e, e, e, e]).pairs.numel() == 0                         # only empty answer sets: never candidates
+    r = run([np.array([1, 2, 3], np.int32)] * 2 + [e])                  # two identical queries + an empty one
+    assert u64(r.pairs).tolist() == [1] and r.val.cpu().tolist() == [1000, 1000]
+    r = run([np.array([5], np.int32)] * 40, K=3)                        # one bucket of 40, K smaller than the degree
+    assert r.pairs.numel() == 40 * 39 // 2 and np.bincount(r.src.cpu().numpy()).tolist() == [3] * 40
+    # top-3 of query 0 under the documented tie-break: all values tie at 1000 -> smallest ids
+    assert r.dst.cpu().numpy()[:3].tolist() == [1, 2, 3]
