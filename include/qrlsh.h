@@ -32,7 +32,7 @@ extern "C" {
 #define QRLSH_OK 0
 #define QRLSH_EINVAL (-1)       /* bad argument (incl. P % b != 0: lsh.py:20 asserts) */
 #define QRLSH_EHIP (-2)         /* a HIP runtime call failed */
-#define QRLSH_EUNSUPPORTED (-3) /* shape outside what the kernels cover (e.g. r > 4) */
+#define QRLSH_EUNSUPPORTED (-3) /* shape outside what the kernels cover */
 #define QRLSH_EWORKSPACE (-4)   /* workspace too small */
 
 #define QRLSH_PERM_U16 0 /* permutation table element = uint16 (D <= 65536) */
@@ -74,8 +74,10 @@ int qrlsh_minhash(const int64_t *offsets, const int32_t *rows, int64_t nq, const
  * band i of a signature = its values [i*r, (i+1)*r) cast to int16 (:28) and joined
  * into a string (:33).  Equal strings <=> equal int16 tuples, so for r <= 4
  *     key = sum_k (sig[i*r + k] & 0xFFFF) << (16 * k)
- * is an exact bucket id.  keys_out is band-major [b][nq].  norm2_out optional.
- * Returns QRLSH_EINVAL if P % b != 0, QRLSH_EUNSUPPORTED if r > 4.
+ * is an exact bucket id.  For r > 4 ("wide bands") the key is a 64-bit hash of the tuple (the all
+ * -1 tuple still maps to ~0): bucket ids are then exact only up to hash collisions, and the
+ * caller must pass the unique pairs through qrlsh_verify_pairs (below) to stay exact.
+ * keys_out is band-major [b][nq].  norm2_out optional.  Returns QRLSH_EINVAL if P % b != 0.
  */
 int qrlsh_band_keys(const int32_t *sig, int64_t nq, int32_t P, int32_t b, uint64_t *keys_out,
                     int64_t *norm2_out, void *stream);
@@ -147,6 +149,10 @@ int qrlsh_unique_fill(const uint64_t *sorted, int64_t n, const void *workspace, 
  *     src << (id_bits + 11) | (1000 - milli) << id_bits | dst        (needs id_bits <= 26)
  */
 int qrlsh_row_norms(const int32_t *sig, int64_t nq, int32_t P, int64_t *norm2_out, void *stream);
+/* exact candidate test (needed only for r = P / b > 4): flags_out[t] = 1 iff pair t shares a band
+ * whose r int16 values are all equal and not all -1 (lsh.py:31-53) */
+int qrlsh_verify_pairs(const void *sig, int32_t sig_dtype, int32_t P, int32_t b, const uint64_t *pairs,
+                       int64_t n, uint8_t *flags_out, void *stream);
 int qrlsh_score_pairs(const void *sig, int32_t sig_dtype, const int64_t *norm2, int32_t P,
                       const uint64_t *pairs, int64_t n, int32_t *milli_out, double *cos_out,
                       uint64_t *edge_out, int32_t id_bits, void *stream);

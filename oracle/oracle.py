@@ -45,6 +45,7 @@ def lib():
             build()
         L = ctypes.CDLL(path)
         L.qro_candidates.restype = ctypes.c_int64
+        L.qro_candidates_from_sig.restype = ctypes.c_int64
         L.qro_emitted_pairs.restype = ctypes.c_int64
         L.qro_topk.restype = ctypes.c_int64
         L.qro_free.argtypes = [ctypes.c_void_p]
@@ -137,6 +138,21 @@ def candidates(keys, r):
     return arr
 
 
+def candidates_from_sig(sig, b):
+    """candidates for ANY band width (buckets grouped by exact int16-tuple comparison):
+    -> sorted unique uint64 array of (i << 32 | j), i < j"""
+    sig = np.ascontiguousarray(sig, dtype=np.int32)
+    nq, P = sig.shape
+    if b <= 0 or P % b != 0:
+        raise AssertionError("signature length %d not divisible by b=%d" % (P, b))
+    out = c_u64p()
+    n = lib().qro_candidates_from_sig(_p(sig, c_i32p), ctypes.c_int64(nq), ctypes.c_int32(P), ctypes.c_int32(b),
+                                      ctypes.byref(out))
+    arr = np.ctypeslib.as_array(out, shape=(max(n, 1),))[:n].copy()
+    lib().qro_free(out)
+    return arr
+
+
 def emitted_pairs(keys, r):
     keys = np.ascontiguousarray(keys, dtype=np.uint64)
     nq, b = keys.shape
@@ -173,8 +189,12 @@ def query_similarities(offsets, rows, D, P, b, K, seed):
     """Whole hot path on the CPU: -> dict with sig, keys, pairs, milli, topk arrays."""
     perm = legacy_permutations(seed, P, D)
     sig = minhash(offsets, rows, perm)
-    keys = band_keys(sig, b)
-    pairs = candidates(keys, P // b)
+    if P // b <= 4:
+        keys = band_keys(sig, b)
+        pairs = candidates(keys, P // b)
+    else:
+        keys = None
+        pairs = candidates_from_sig(sig, b)
     milli = score_pairs(sig, pairs, mode=1)
     src, dst, val = topk(pairs, milli, K)
     return dict(sig=sig, keys=keys, pairs=pairs, milli=milli, src=src, dst=dst, val=val)

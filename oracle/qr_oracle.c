@@ -224,6 +224,70 @@ QRO_API int64_t qro_candidates(const uint64_t *keys, int64_t nq, int32_t b, int3
   return u;
 }
 
+/* Same as qro_candidates, for ANY band width r = P / b: buckets are grouped by comparing the
+ * int16 tuples themselves (no 64-bit packing), straight from the signature matrix. */
+typedef struct { const int32_t *sig; int32_t P, off, r; } tuple_ctx_t;
+static __thread tuple_ctx_t g_tc;
+static int cmp_tuple(const void *a, const void *b) {
+  const uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b;
+  const int32_t *sx = g_tc.sig + (size_t)x * g_tc.P + g_tc.off, *sy = g_tc.sig + (size_t)y * g_tc.P + g_tc.off;
+  for (int32_t t = 0; t < g_tc.r; ++t) {
+    const uint32_t vx = (uint32_t)sx[t] & 0xFFFFu, vy = (uint32_t)sy[t] & 0xFFFFu;
+    if (vx != vy) return vx < vy ? -1 : 1;
+  }
+  return x < y ? -1 : (x > y);
+}
+
+QRO_API int64_t qro_candidates_from_sig(const int32_t *sig, int64_t nq, int32_t P, int32_t b, uint64_t **pairs_out) {
+  *pairs_out = NULL;
+  if (nq < 0 || b <= 0 || P % b != 0) return -1;
+  const int32_t r = P / b;
+  uint32_t *idx = (uint32_t *)malloc((size_t)(nq > 0 ? nq : 1) * sizeof(uint32_t));
+  uint64_t *all = NULL;
+  int64_t n = 0, cap = 0;
+  for (int32_t band = 0; band < b; ++band) {
+    for (int64_t q = 0; q < nq; ++q) idx[q] = (uint32_t)q;
+    g_tc.sig = sig; g_tc.P = P; g_tc.off = band * r; g_tc.r = r;
+    qsort(idx, (size_t)nq, sizeof(uint32_t), cmp_tuple);
+    int64_t s = 0;
+    while (s < nq) {
+      int64_t e = s + 1;
+      const int32_t *ss = sig + (size_t)idx[s] * P + band * r;
+      while (e < nq) {
+        const int32_t *se = sig + (size_t)idx[e] * P + band * r;
+        int same = 1;
+        for (int32_t t = 0; t < r; ++t)
+          if (((uint32_t)ss[t] & 0xFFFFu) != ((uint32_t)se[t] & 0xFFFFu)) { same = 0; break; }
+        if (!same) break;
+        ++e;
+      }
+      int empty = 1;
+      for (int32_t t = 0; t < r; ++t)
+        if (((uint32_t)ss[t] & 0xFFFFu) != 0xFFFFu) { empty = 0; break; }
+      const int64_t m = e - s;
+      if (m > 1 && !empty) {
+        const int64_t need = n + m * (m - 1) / 2;
+        if (need > cap) {
+          cap = cap ? cap : 1024;
+          while (cap < need) cap *= 2;
+          all = (uint64_t *)realloc(all, (size_t)cap * sizeof(uint64_t));
+        }
+        for (int64_t x = s; x < e; ++x)
+          for (int64_t y = x + 1; y < e; ++y) all[n++] = ((uint64_t)idx[x] << 32) | idx[y];
+      }
+      s = e;
+    }
+  }
+  free(idx);
+  if (!all) all = (uint64_t *)malloc(sizeof(uint64_t));
+  radix_sort_u64(all, n);
+  int64_t u = 0;
+  for (int64_t i = 0; i < n; ++i)
+    if (i == 0 || all[i] != all[i - 1]) all[u++] = all[i];
+  *pairs_out = all;
+  return u;
+}
+
 /* number of pairs before cross-band de-duplication (what the per-band
  * combinations() loops generate in total, lsh.py:49) */
 QRO_API int64_t qro_emitted_pairs(const uint64_t *keys, int64_t nq, int32_t b, int32_t r) {

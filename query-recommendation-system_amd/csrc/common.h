@@ -56,6 +56,29 @@ __host__ __device__ static inline uint64_t qr_empty_key(int r) {
   return r >= 4 ? ~0ull : ((1ull << (16 * r)) - 1ull);
 }
 
+// Band key from the r low-16 values of one band (lsh.py:28-34).  r <= 4: the tuple itself,
+// packed -- an exact bucket id.  r > 4 ("wide band"): a 64-bit hash of the tuple; buckets can
+// then (with probability ~2^-64 per pair) merge distinct tuples, so the host runs
+// qrlsh_verify_pairs on the unique pairs afterwards and the result stays exact.  The all -1
+// tuple always maps to ~0 and nothing else does.
+__device__ static inline uint64_t qr_make_key(const uint16_t *s, int r) {
+  if (r <= 4) {
+    uint64_t k = 0;
+    for (int j = 0; j < r; ++j) k |= (uint64_t)s[j] << (16 * j);
+    return k;
+  }
+  uint64_t h = 0x243F6A8885A308D3ull;
+  bool empty = true;
+  for (int j = 0; j < r; ++j) {
+    h = (h ^ s[j]) * 0x9E3779B97F4A7C15ull;
+    h ^= h >> 29;
+    empty &= s[j] == 0xFFFFu;
+  }
+  h = qr_mix64(h);
+  if (empty) return ~0ull;
+  return h == ~0ull ? h - 1 : h;
+}
+
 __device__ static inline int lane_id() { return threadIdx.x & (WAVE - 1); }
 
 // wave-level inclusive scan of a u64 via shuffles

@@ -149,10 +149,7 @@ __global__ __launch_bounds__(256) void minhash_kernel(const int64_t *__restrict_
     for (int idx = threadIdx.x; idx < qpb * b; idx += blockDim.x) {
       const int ql = idx % qpb, band = idx / qpb;
       if (ql < nql) {
-        const uint16_t *s = s16 + ql * ldk + band * r;
-        uint64_t k = 0;
-        for (int j = 0; j < r; ++j) k |= (uint64_t)s[j] << (16 * j);
-        keys[(size_t)band * nq + q0 + ql] = k;
+        keys[(size_t)band * nq + q0 + ql] = qr_make_key(s16 + ql * ldk + band * r, r);
       }
     }
   }
@@ -253,10 +250,7 @@ __global__ __launch_bounds__(256) void minhash_group_kernel(const int64_t *__res
     for (int idx = threadIdx.x; idx < QPB * b; idx += blockDim.x) {
       const int ql = idx % QPB, band = idx / QPB;
       if (ql < nql) {
-        const uint16_t *sp = s16 + ql * ldk + band * r;
-        uint64_t k = 0;
-        for (int j = 0; j < r; ++j) k |= (uint64_t)sp[j] << (16 * j);
-        keys[(size_t)band * nq + q0 + ql] = k;
+        keys[(size_t)band * nq + q0 + ql] = qr_make_key(s16 + ql * ldk + band * r, r);
       }
     }
   }
@@ -279,10 +273,7 @@ __global__ __launch_bounds__(256) void band_keys_kernel(const int32_t *__restric
   for (int idx = threadIdx.x; idx < qpb * b; idx += blockDim.x) {
     const int ql = idx % qpb, band = idx / qpb;
     if (ql < nql) {
-      const uint16_t *s = s16 + ql * ldk + band * r;
-      uint64_t k = 0;
-      for (int j = 0; j < r; ++j) k |= (uint64_t)s[j] << (16 * j);
-      keys[(size_t)band * nq + q0 + ql] = k;
+      keys[(size_t)band * nq + q0 + ql] = qr_make_key(s16 + ql * ldk + band * r, r);
     }
   }
 }
@@ -365,10 +356,6 @@ QRLSH_EXPORT int qrlsh_minhash(const int64_t *offsets, const int32_t *rows, int6
   if (keys_out) {
     QR_CHECK_ARG(b > 0 && P % b == 0, "qrlsh_minhash: signature length %d not divisible by b=%d", P, b);
     r = P / b;
-    if (r > 4) {
-      qrlsh_set_error("qrlsh_minhash: band width r=%d > 4 does not fit the 64-bit key", r);
-      return QRLSH_EUNSUPPORTED;
-    }
   }
   if (nq == 0) return QRLSH_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -384,10 +371,6 @@ QRLSH_EXPORT int qrlsh_band_keys(const int32_t *sig, int64_t nq, int32_t P, int3
   QR_CHECK_ARG(nq >= 0 && P > 0 && (nq == 0 || (sig && keys_out)), "qrlsh_band_keys: bad arguments");
   QR_CHECK_ARG(b > 0 && P % b == 0, "qrlsh_band_keys: signature length %d not divisible by b=%d", P, b);
   const int r = P / b;
-  if (r > 4) {
-    qrlsh_set_error("qrlsh_band_keys: band width r=%d > 4 does not fit the 64-bit key", r);
-    return QRLSH_EUNSUPPORTED;
-  }
   if (nq == 0) return QRLSH_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int qpb = pick_qpb(P);

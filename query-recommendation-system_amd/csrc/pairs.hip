@@ -223,7 +223,7 @@ QRLSH_EXPORT size_t qrlsh_pairs_workspace_bytes(int64_t nq, int32_t b) {
 QRLSH_EXPORT int qrlsh_pairs_count(const uint64_t *sorted_keys, int64_t nq, int32_t b, int32_t r, int32_t hash_bits,
                                    void *workspace,
                                    size_t workspace_bytes, uint64_t *total_out, void *stream) {
-  QR_CHECK_ARG(nq >= 0 && b > 0 && r > 0 && r <= 4, "qrlsh_pairs_count: bad sizes nq=%lld b=%d r=%d", (long long)nq,
+  QR_CHECK_ARG(nq >= 0 && b > 0 && r > 0, "qrlsh_pairs_count: bad sizes nq=%lld b=%d r=%d", (long long)nq,
                b, r);
   QR_CHECK_ARG(hash_bits >= 8 && hash_bits <= 32, "qrlsh_pairs_count: hash_bits=%d not in [8,32]", hash_bits);
   QR_CHECK_ARG(total_out && workspace, "qrlsh_pairs_count: null pointer");
@@ -253,7 +253,7 @@ QRLSH_EXPORT int qrlsh_pairs_count(const uint64_t *sorted_keys, int64_t nq, int3
 QRLSH_EXPORT int qrlsh_pairs_fill(const uint64_t *sorted_keys, const uint32_t *sorted_ids, int64_t nq, int32_t b,
                                   int32_t r, int32_t hash_bits, const void *workspace, uint64_t *pairs_out,
                                   void *stream) {
-  QR_CHECK_ARG(nq >= 0 && b > 0 && r > 0 && r <= 4 && hash_bits >= 8 && hash_bits <= 32, "qrlsh_pairs_fill: bad sizes");
+  QR_CHECK_ARG(nq >= 0 && b > 0 && r > 0 && hash_bits >= 8 && hash_bits <= 32, "qrlsh_pairs_fill: bad sizes");
   if (nq == 0) return QRLSH_OK;
   QR_CHECK_ARG(sorted_keys && sorted_ids && workspace && pairs_out, "qrlsh_pairs_fill: null pointer");
   const int ntiles = (int)ceil_div64(nq, PAIR_TILE);

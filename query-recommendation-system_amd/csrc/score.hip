@@ -122,3 +122,47 @@ QRLSH_EXPORT int qrlsh_score_pairs(const void *sig, int32_t sig_dtype, const int
   QR_LAUNCH_CHECK("qrlsh_score_pairs");
   return QRLSH_OK;
 }
+
+// Exact candidate test for wide bands (r > 4, hashed bucket ids): flags[t] = 1 iff the pair
+// shares at least one band whose r low-16 values are all equal and not all -1 -- the condition
+// lsh.py:31-53 implements with string keys.  One thread per pair; only used on the r > 4 path.
+template <typename SigT>
+__global__ __launch_bounds__(256) void verify_pairs_kernel(const SigT *__restrict__ sig, int P, int b,
+                                                           const uint64_t *__restrict__ pairs, int64_t n,
+                                                           uint8_t *__restrict__ flags) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const uint64_t pr = pairs[t];
+  const SigT *a = sig + (size_t)(uint32_t)(pr >> 32) * P;
+  const SigT *c = sig + (size_t)(uint32_t)pr * P;
+  const int r = P / b;
+  uint8_t hit = 0;
+  for (int band = 0; band < b && !hit; ++band) {
+    bool eq = true, empty = true;
+    for (int k = 0; k < r; ++k) {
+      const uint32_t x = (uint32_t)a[band * r + k] & 0xFFFFu, y = (uint32_t)c[band * r + k] & 0xFFFFu;
+      eq &= x == y;
+      empty &= x == 0xFFFFu;
+    }
+    hit = eq && !empty;
+  }
+  flags[t] = hit;
+}
+
+QRLSH_EXPORT int qrlsh_verify_pairs(const void *sig, int32_t sig_dtype, int32_t P, int32_t b, const uint64_t *pairs,
+                                    int64_t n, uint8_t *flags_out, void *stream) {
+  QR_CHECK_ARG(n >= 0 && P > 0 && b > 0 && P % b == 0, "qrlsh_verify_pairs: bad sizes n=%lld P=%d b=%d", (long long)n, P, b);
+  QR_CHECK_ARG(sig_dtype == QRLSH_SIG_I32 || sig_dtype == QRLSH_SIG_U16, "qrlsh_verify_pairs: bad sig_dtype %d", sig_dtype);
+  if (n == 0) return QRLSH_OK;
+  QR_CHECK_ARG(sig && pairs && flags_out, "qrlsh_verify_pairs: null pointer");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)ceil_div64(n, 256)), block(256);
+  if (sig_dtype == QRLSH_SIG_U16)
+    QR_LAUNCH("verify_pairs", (verify_pairs_kernel<uint16_t>), grid, block, 0, st, static_cast<const uint16_t *>(sig), P, b,
+              pairs, n, flags_out);
+  else
+    QR_LAUNCH("verify_pairs", (verify_pairs_kernel<int32_t>), grid, block, 0, st, static_cast<const int32_t *>(sig), P, b,
+              pairs, n, flags_out);
+  QR_LAUNCH_CHECK("qrlsh_verify_pairs");
+  return QRLSH_OK;
+}

@@ -494,7 +494,7 @@ QRLSH_EXPORT int qrlsh_bucket_pairs_count(const uint64_t *keys, uint64_t *part_k
                                           uint64_t *tmp_keys, uint32_t *tmp_ids, int64_t nq, int32_t b, int32_t r,
                                           int32_t part_bits, void *workspace, size_t workspace_bytes,
                                           uint64_t *total_overflow_out, void *stream) {
-  QR_CHECK_ARG(nq >= 0 && b > 0 && b <= 65535 && r > 0 && r <= 4, "qrlsh_bucket_pairs_count: bad sizes nq=%lld b=%d r=%d",
+  QR_CHECK_ARG(nq >= 0 && b > 0 && b <= 65535 && r > 0, "qrlsh_bucket_pairs_count: bad sizes nq=%lld b=%d r=%d",
                (long long)nq, b, r);
   QR_CHECK_ARG(part_bits >= 8 && part_bits <= 16, "qrlsh_bucket_pairs_count: part_bits=%d not in [8,16]", part_bits);
   QR_CHECK_ARG(nq < (1ll << 32), "qrlsh_bucket_pairs_count: nq too large");
@@ -552,7 +552,7 @@ QRLSH_EXPORT int qrlsh_bucket_pairs_count(const uint64_t *keys, uint64_t *part_k
 QRLSH_EXPORT int qrlsh_bucket_pairs_fill(const uint64_t *part_keys, const uint32_t *part_ids, int64_t nq, int32_t b,
                                          int32_t r, int32_t part_bits, void *workspace, uint64_t *pairs_out,
                                          void *stream) {
-  QR_CHECK_ARG(nq >= 0 && b > 0 && r > 0 && r <= 4 && part_bits >= 8 && part_bits <= 16,
+  QR_CHECK_ARG(nq >= 0 && b > 0 && r > 0 && part_bits >= 8 && part_bits <= 16,
                "qrlsh_bucket_pairs_fill: bad sizes");
   if (nq == 0) return QRLSH_OK;
   QR_CHECK_ARG(part_keys && part_ids && workspace && pairs_out, "qrlsh_bucket_pairs_fill: null pointer");

@@ -97,7 +97,7 @@ class LSH:
         if n == 0:
             return torch.empty((0,), dtype=torch.int64, device=self.device)
         keys = ops.band_keys(sig, self.b)
-        return ops.candidate_pairs(keys, P // self.b, stats)
+        return ops.candidate_pairs(keys, P // self.b, stats, sig=sig)
 
     # -- internals ---------------------------------------------------------------
     def _to_device(self, a):
@@ -113,23 +113,17 @@ class LSH:
             self._host_sigs = []
 
     def _materialise_buckets(self):
-        sig = self.signatures_tensor()
+        """The reference's `buckets` attribute (list of b dicts "v0,v1,.." -> [ids]), rebuilt on
+        request from the registered signatures; insertion order = first appearance by id."""
+        sig = ops.sig_to_int32(self.signatures_tensor()).cpu().numpy()
         out = [dict() for _ in range(self.b)]
         n, P = sig.shape
         if n == 0:
             return out
         r = P // self.b
-        sk, sid = ops.bucket_sort(ops.band_keys(sig, self.b))
-        sk = sk.cpu().numpy().view(np.uint64)
-        sid = sid.cpu().numpy()
+        sub = (sig.astype(np.int64) & 0xFFFF).astype(np.uint16).view(np.int16).reshape(n, self.b, r)
         for band in range(self.b):
-            k, ids = sk[band], sid[band]
-            # runs of equal mix are adjacent; group by full key (collisions interleave)
-            d = {}
-            for key, q in zip(k.tolist(), ids.tolist()):
-                d.setdefault(key, []).append(q)
-            # dict insertion order of the reference = first appearance by query id
-            for key, hits in sorted(d.items(), key=lambda kv: kv[1][0]):
-                vals = [np.int16(np.uint16((key >> (16 * j)) & 0xFFFF)) for j in range(r)]
-                out[band][",".join(str(int(v)) for v in vals)] = sorted(hits)
+            d = out[band]
+            for q in range(n):
+                d.setdefault(",".join(str(int(v)) for v in sub[q, band]), []).append(q)
         return out

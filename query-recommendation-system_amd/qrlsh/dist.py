@@ -49,6 +49,9 @@ class HipBackend:
     def sort_words(self, words, lo, hi):
         return ops.sort_u64(words, None, lo, hi)[0]
 
+    def verify(self, sig_all, b, pairs):
+        return ops.drop_unverified(sig_all, b, pairs)
+
     def score(self, sig_all, norm_all, pairs, id_bits):
         milli, _, edges = ops.score_pairs(sig_all, norm_all, pairs, edge_id_bits=id_bits)
         return milli, edges
@@ -207,6 +210,8 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
     # 6. score on the owner; reverse edges -> owner of j
     h_sig.wait()
     h_nrm.wait()
+    if r > 4 and pairs.numel():   # wide bands: hashed bucket ids -> exact verification on the owner
+        pairs = be.verify(sig_all, b, pairs)
     milli, edges = be.score(sig_all, norm_all, pairs, ib)
     fwd = edges[0::2].contiguous()
     rev = be.sort_words(edges[1::2].contiguous(), ib + 11, 2 * ib + 11) if pairs.numel() else edges[1::2].contiguous()

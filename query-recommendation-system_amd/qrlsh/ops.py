@@ -302,16 +302,49 @@ def emit_pairs_any(keys, r, stats=None):
     return emitted
 
 
-def candidate_pairs(keys, r, stats=None):
+def verify_pairs(sig, b, pairs):
+    """Exact candidate test of lsh.py:31-53 per pair (shares a non-empty band): uint8 flags.
+    Needed only for wide bands (r = P / b > 4), whose bucket ids are hashes."""
+    lib = _lib.load()
+    if not isinstance(sig, torch.Tensor) or sig.dtype not in (torch.int32, torch.int16):
+        raise TypeError("sig must be an int32 or int16 (compact) tensor")
+    _need(sig, sig.dtype, "sig", 2)
+    _need(pairs, torch.int64, "pairs", 1)
+    n = pairs.numel()
+    flags = torch.empty((n,), dtype=torch.uint8, device=sig.device)
+    code = _lib.SIG_U16 if sig.dtype == torch.int16 else _lib.SIG_I32
+    _lib.check(lib.qrlsh_verify_pairs(_ptr(sig), code, sig.shape[1], b, _ptr(pairs), n, _ptr(flags), _stream()))
+    return flags
+
+
+def drop_unverified(sig, b, pairs, stats=None):
+    """wide bands: keep only the pairs that really share a band (hash collisions of the bucket
+    ids, astronomically rare, are removed here so the candidate set stays exact)"""
+    if pairs.numel() == 0:
+        return pairs
+    flags = verify_pairs(sig, b, pairs)
+    bad = int((flags == 0).sum().item())
+    if stats is not None:
+        stats["hash_collision_pairs_dropped"] = bad
+    return pairs if bad == 0 else pairs[flags.bool()]
+
+
+def candidate_pairs(keys, r, stats=None, sig=None):
     """get_candidates (lsh.py:40-55) on band-major keys [b,nq] (consumed): sorted unique
-    int64 array of i<<32|j, i<j."""
+    int64 array of i<<32|j, i<j.  For wide bands (r > 4) pass the signature matrix `sig`: the
+    hashed bucket ids are verified against it."""
     b, nq = keys.shape
+    if r > 4 and sig is None:
+        raise ValueError("band width r=%d > 4 needs the signatures for exact verification" % r)
     emitted = emit_pairs_any(keys, r, stats)
     if stats is not None:
         stats["emitted_pairs"] = int(emitted.numel())
     if emitted.numel() == 0:
         return emitted
-    return unique_sorted(sort_pairs(emitted, nq))
+    pairs = unique_sorted(sort_pairs(emitted, nq))
+    if r > 4:
+        pairs = drop_unverified(sig, b, pairs, stats)
+    return pairs
 
 
 # ---------------------------------------------------------------------------

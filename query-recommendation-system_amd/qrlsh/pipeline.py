@@ -76,7 +76,7 @@ def query_similarities(offsets, rows, table, b, K, timings=None, compact=None):
         compact = ops.can_compact(table)   # uint16 signature rows whenever they are lossless
     sig, norm2, keys = ops.minhash(offsets, rows, table, b=b, want_norm=True, compact=compact)
     t0 = tick("signatures", t0)
-    pairs = ops.candidate_pairs(keys, r, stats)
+    pairs = ops.candidate_pairs(keys, r, stats, sig=sig)
     del keys
     t0 = tick("candidates", t0)
     ib = ops.id_bits_for(nq)

@@ -5,8 +5,9 @@ import numpy as np
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
-FULL = ["cfg1_hotpath", "full_p180", "full_p160", "full_p320", "full_p200", "full_p160_wrap", "full_p160_ties"]
-PIECES = ["pieces_p128_b32", "pieces_p256_b64", "pieces_p128_b32_wrap"]
+FULL = ["cfg1_hotpath", "full_p180", "full_p160", "full_p320", "full_p200", "full_p160_wrap", "full_p160_ties",
+        "full_p100_r5", "full_p50_r5_wrap"]   # the last two: wide bands (r = 5), the reference's pick for PERM = 100 / 50
+PIECES = ["pieces_p128_b32", "pieces_p256_b64", "pieces_p128_b32_wrap", "pieces_p96_b12"]   # last: r = 8
 
 
 def load(name):

@@ -39,7 +39,16 @@ def test_minhash_matches_reference_golden(name, force_i32):
     torch.cuda.synchronize()
     assert np.array_equal(sig.cpu().numpy(), g["sig"])
     assert np.array_equal(norm2.cpu().numpy(), (g["sig"].astype(np.int64) ** 2).sum(1))
-    assert np.array_equal(u64(keys).T, O.band_keys(g["sig"], b))
+    if P // b <= 4:
+        assert np.array_equal(u64(keys).T, O.band_keys(g["sig"], b))
+    else:   # wide bands: hashed bucket ids -- equal tuples <=> equal ids on this data, empty tuple -> ~0
+        lo = (g["sig"].astype(np.int64) & 0xFFFF).reshape(len(g["sig"]), b, P // b)
+        k = u64(keys).T
+        for band in (0, b - 1):
+            _, inv_t = np.unique(lo[:, band, :], axis=0, return_inverse=True)
+            _, inv_k = np.unique(k[:, band], return_inverse=True)
+            assert len(set(zip(inv_t.ravel().tolist(), inv_k.ravel().tolist()))) == inv_t.max() + 1 == inv_k.max() + 1
+        assert np.all(k[np.all(lo == 0xFFFF, axis=2)] == np.uint64(0xFFFFFFFFFFFFFFFF))
     # standalone a2 agrees with the fused one
     k2, n2 = ops.band_keys(sig, b, want_norm=True)
     assert torch.equal(k2, keys) and torch.equal(n2, norm2)
@@ -76,9 +85,8 @@ def test_minhash_empty_input_and_errors():
     assert sig.shape == (0, 8) and keys.shape == (4, 0)
     with pytest.raises(AssertionError):
         ops.minhash(dev(np.zeros(2, np.int64)), dev(np.zeros(0, np.int32)), table, b=3)
-    table16 = ops.perm_table(O.legacy_permutations(0, 16, 16), DEV)
-    with pytest.raises(NotImplementedError):  # r = 8 > 4
-        ops.minhash(dev(np.zeros(2, np.int64)), dev(np.zeros(0, np.int32)), table16, b=2)
+    with pytest.raises(ValueError):           # wide bands need the signatures for verification
+        ops.candidate_pairs(dev(np.zeros((2, 4), np.int64)), 5)
 
 
 # ---------------------------------------------------------------------------- sort
@@ -137,7 +145,10 @@ def test_candidates_match_reference_golden(name):
     stats = {}
     arr = l.get_candidates_array(stats)
     assert np.array_equal(u64(arr), np.sort(pairs_u64(g["pairs"])))
-    assert stats["emitted_pairs"] == O.emitted_pairs(O.band_keys(g["sig"], int(g["b"])), int(g["P"]) // int(g["b"]))
+    if int(g["P"]) // int(g["b"]) <= 4:
+        assert stats["emitted_pairs"] == O.emitted_pairs(O.band_keys(g["sig"], int(g["b"])), int(g["P"]) // int(g["b"]))
+    else:
+        assert stats["hash_collision_pairs_dropped"] == 0
 
 
 def test_lsh_dropin_surface_and_edge_semantics():
@@ -288,7 +299,7 @@ def test_synth_generator_matches_oracle_twin():
 
 
 @pytest.mark.parametrize("nq,D,P,b", [(20000, 32768, 128, 32), (30000, 100000, 128, 32), (12000, 32768, 256, 64),
-                                      (200000, 32768, 128, 32)])
+                                      (200000, 32768, 128, 32), (25000, 32768, 100, 20), (9000, 70000, 96, 12)])
 def test_pipeline_equals_oracle_on_synthetic(nq, D, P, b):
     K = pipeline.max_candidates(nq)
     off, rows = qrlsh.synth_csr(nq, D, seed=0, device=DEV)
@@ -298,7 +309,7 @@ def test_pipeline_equals_oracle_on_synthetic(nq, D, P, b):
     ho, hr = off.cpu().numpy(), rows.cpu().numpy()
     sig = O.minhash(ho, hr, perms)
     assert np.array_equal(res.sig_int32().cpu().numpy(), sig)
-    pairs = O.candidates(O.band_keys(sig, b), P // b)
+    pairs = O.candidates_from_sig(sig, b)
     assert np.array_equal(u64(res.pairs), pairs)
     milli = O.score_pairs(sig, pairs, mode=1)
     assert np.array_equal(res.milli.cpu().numpy(), milli)
@@ -463,3 +474,19 @@ def test_pipeline_degenerate_inputs():
     assert r.pairs.numel() == 40 * 39 // 2 and np.bincount(r.src.cpu().numpy()).tolist() == [3] * 40
     # top-3 of query 0 under the documented tie-break: all values tie at 1000 -> smallest ids
     assert r.dst.cpu().numpy()[:3].tolist() == [1, 2, 3]
+
+
+def test_verify_pairs_is_the_exact_candidate_predicate():
+    g = load("pieces_p96_b12")                                   # r = 8
+    sig, b = g["sig"], int(g["b"])
+    n = len(sig)
+    rng = np.random.default_rng(4)
+    true_pairs = pairs_u64(g["pairs"])
+    rnd = np.array([(min(i, j) << 32) | max(i, j) for i, j in rng.integers(0, n, size=(3000, 2)) if i != j], dtype=np.uint64)
+    allp = np.unique(np.concatenate([true_pairs, rnd]))
+    truth = np.isin(allp, true_pairs)
+    for s_dev in (dev(sig), dev(np.where(sig < 0, 0xFFFF, sig).astype(np.uint16).view(np.int16))):
+        flags = ops.verify_pairs(s_dev, b, dev(allp.view(np.int64))).cpu().numpy().astype(bool)
+        assert np.array_equal(flags, truth)
+        kept = ops.drop_unverified(s_dev, b, dev(allp.view(np.int64)))
+        assert np.array_equal(u64(kept), true_pairs)

@@ -17,7 +17,9 @@ How the reference is run:
     ./input/* and writes ./output/*), with a pandas-backed `dt.fread`.
   * sys.dont_write_bytecode keeps __pycache__ out of the read-only reference tree.
 
-Usage:  python tools/make_golden.py            (rewrites every fixture)
+Usage:  python tools/make_golden.py            (rewrites the round-1 base fixtures)
+        python tools/make_golden.py NAME...    (only the named later additions: full_p100_r5,
+                                                full_p50_r5_wrap, pieces_p96_b12)
 """
 import os
 import sys
@@ -385,6 +387,23 @@ def main():
     import recommender as recommender_mod
     sys.path.pop(0)
 
+    only = set(sys.argv[1:])
+
+    def want(name):
+        return not only or name in only
+
+    if only:
+        # wide bands: PERM=100 makes the reference's rule pick b=20, r=5 (recommender.py:156-163)
+        if want("full_p100_r5"):
+            fixture_full(recommender_mod, lsh_mod, "full_p100_r5", nq=700, D=2500, P=100, seed=19, data_seed=7,
+                         n_empty=4, n_dup=5)
+        if want("full_p50_r5_wrap"):
+            fixture_full(recommender_mod, lsh_mod, "full_p50_r5_wrap", nq=400, D=90000, P=50, seed=23, data_seed=9,
+                         n_empty=2, n_dup=3, cluster=6, mean=8)
+        if want("pieces_p96_b12"):
+            fixture_pieces(recommender_mod, lsh_mod, "pieces_p96_b12", nq=500, D=3000, P=96, b=12, seed=29,
+                           data_seed=10, n_empty=3, n_dup=3, p_replace=0.05)
+        return
     fixture_generator_default(recommender_mod, lsh_mod)
     # shapes the reference's own band rule selects (recommender.py:151-165)
     fixture_full(recommender_mod, lsh_mod, "full_p180", nq=1200, D=4096, P=180, seed=42, data_seed=1)
