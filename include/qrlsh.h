@@ -147,6 +147,8 @@ int qrlsh_unique_fill(const uint64_t *sorted, int64_t n, const void *workspace, 
  * cos_out (double, unrounded) and edge_out are optional.  edge_out[2n] receives the two
  * directed top-K sort keys of each pair:
  *     src << (id_bits + 11) | (1000 - milli) << id_bits | dst        (needs id_bits <= 26)
+ * or, when edge_dst_out[2n] is given (any id width, "wide ids"),
+ *     edge_out = src << 11 | (1000 - milli),  edge_dst_out = dst   (a key + payload record).
  */
 int qrlsh_row_norms(const int32_t *sig, int64_t nq, int32_t P, int64_t *norm2_out, void *stream);
 /* exact candidate test (needed only for r = P / b > 4): flags_out[t] = 1 iff pair t shares a band
@@ -155,19 +157,20 @@ int qrlsh_verify_pairs(const void *sig, int32_t sig_dtype, int32_t P, int32_t b,
                        int64_t n, uint8_t *flags_out, void *stream);
 int qrlsh_score_pairs(const void *sig, int32_t sig_dtype, const int64_t *norm2, int32_t P,
                       const uint64_t *pairs, int64_t n, int32_t *milli_out, double *cos_out,
-                      uint64_t *edge_out, int32_t id_bits, void *stream);
+                      uint64_t *edge_out, int32_t id_bits, uint32_t *edge_dst_out, void *stream);
 
 /* ---- a5: per-query top-K -----------------------------------------------------------
  * Replaces argsort(values)[::-1][:K] per query, recommender.py:206-210, on the edge keys
  * sorted ascending (so: src, value descending, dst ascending -- the documented
  * tie-break; the reference's own tie order is arbitrary).  count-then-fill; the output
- * is COO (src, dst, milli), at most K rows per src.
+ * is COO (src, dst, milli), at most K rows per src.  Wide-id edges: id_bits = 0 and sorted_dst =
+ * the payload sorted along with the keys (NULL for the packed format).
  */
 int qrlsh_topk_count(const uint64_t *sorted_edges, int64_t n_edges, int32_t K, int32_t id_bits,
                      void *workspace, size_t workspace_bytes, uint64_t *total_out, void *stream);
-int qrlsh_topk_fill(const uint64_t *sorted_edges, int64_t n_edges, int32_t K, int32_t id_bits,
-                    const void *workspace, int32_t *src_out, int32_t *dst_out, int32_t *milli_out,
-                    void *stream);
+int qrlsh_topk_fill(const uint64_t *sorted_edges, const uint32_t *sorted_dst, int64_t n_edges, int32_t K,
+                    int32_t id_bits, const void *workspace, int32_t *src_out, int32_t *dst_out,
+                    int32_t *milli_out, void *stream);
 
 /* ---- N2: answer sets (the producer of the hot path's input) ---------------------------------
  * Replaces Recommender.compute_shingles, recommender.py:68-103, for queries that are

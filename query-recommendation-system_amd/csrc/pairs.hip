@@ -173,6 +173,7 @@ __global__ __launch_bounds__(CMP_THREADS) void compact_count_kernel(const uint64
 template <int PRED>
 __global__ __launch_bounds__(CMP_THREADS) void compact_fill_kernel(const uint64_t *__restrict__ a, int64_t n, int K,
                                                                    int sh, int id_bits,
+                                                                   const uint32_t *__restrict__ vals,
                                                                    const uint64_t *__restrict__ blk,
                                                                    uint64_t *__restrict__ out_u64,
                                                                    int32_t *__restrict__ src_out,
@@ -206,8 +207,13 @@ __global__ __launch_bounds__(CMP_THREADS) void compact_fill_kernel(const uint64_
         out_u64[p] = v[i];
       } else {
         src_out[p] = (int32_t)(v[i] >> sh);
-        dst_out[p] = (int32_t)(v[i] & idm);
-        milli_out[p] = 1000 - (int32_t)((v[i] >> id_bits) & 0x7FFull);
+        if (vals) {  // wide ids: key = src << 11 | inv, dst rides as the payload
+          dst_out[p] = (int32_t)vals[base + i * WAVE + lane];
+          milli_out[p] = 1000 - (int32_t)(v[i] & 0x7FFull);
+        } else {
+          dst_out[p] = (int32_t)(v[i] & idm);
+          milli_out[p] = 1000 - (int32_t)((v[i] >> id_bits) & 0x7FFull);
+        }
       }
     }
     pos += (uint64_t)__popcll(masks[i]);
@@ -307,29 +313,31 @@ QRLSH_EXPORT int qrlsh_unique_fill(const uint64_t *sorted, int64_t n, const void
   if (n == 0) return QRLSH_OK;
   QR_CHECK_ARG(sorted && workspace && out, "qrlsh_unique_fill: null pointer");
   QR_LAUNCH("unique_fill", (compact_fill_kernel<PRED_UNIQUE>), dim3((unsigned)ceil_div64(n, CMP_TILE)), dim3(CMP_THREADS), 0,
-                     static_cast<hipStream_t>(stream), sorted, n, 0, 0, 0, static_cast<const uint64_t *>(workspace),
-                     out, nullptr, nullptr, nullptr);
+                     static_cast<hipStream_t>(stream), sorted, n, 0, 0, 0, (const uint32_t *)nullptr,
+                     static_cast<const uint64_t *>(workspace), out, nullptr, nullptr, nullptr);
   QR_LAUNCH_CHECK("qrlsh_unique_fill");
   return QRLSH_OK;
 }
 
 QRLSH_EXPORT int qrlsh_topk_count(const uint64_t *sorted_edges, int64_t n_edges, int32_t K, int32_t id_bits,
                                   void *workspace, size_t workspace_bytes, uint64_t *total_out, void *stream) {
-  QR_CHECK_ARG(K > 0 && id_bits > 0 && id_bits <= 26, "qrlsh_topk_count: bad K=%d or id_bits=%d (need <= 26)", K,
+  // id_bits == 0 selects the wide-id edge format (src << 11 | inv, dst as payload)
+  QR_CHECK_ARG(K > 0 && id_bits >= 0 && id_bits <= 26, "qrlsh_topk_count: bad K=%d or id_bits=%d (need <= 26)", K,
                id_bits);
   return compact_count<PRED_TOPK>(sorted_edges, n_edges, K, id_bits + 11, workspace, workspace_bytes, total_out, stream,
                                   "qrlsh_topk_count");
 }
 
-QRLSH_EXPORT int qrlsh_topk_fill(const uint64_t *sorted_edges, int64_t n_edges, int32_t K, int32_t id_bits,
-                                 const void *workspace, int32_t *src_out, int32_t *dst_out, int32_t *milli_out,
-                                 void *stream) {
-  QR_CHECK_ARG(K > 0 && id_bits > 0 && id_bits <= 26 && n_edges >= 0, "qrlsh_topk_fill: bad arguments");
+QRLSH_EXPORT int qrlsh_topk_fill(const uint64_t *sorted_edges, const uint32_t *sorted_dst, int64_t n_edges, int32_t K,
+                                 int32_t id_bits, const void *workspace, int32_t *src_out, int32_t *dst_out,
+                                 int32_t *milli_out, void *stream) {
+  QR_CHECK_ARG(K > 0 && id_bits >= 0 && id_bits <= 26 && n_edges >= 0, "qrlsh_topk_fill: bad arguments");
+  QR_CHECK_ARG((id_bits == 0) == (sorted_dst != nullptr), "qrlsh_topk_fill: sorted_dst goes with id_bits == 0");
   if (n_edges == 0) return QRLSH_OK;
   QR_CHECK_ARG(sorted_edges && workspace && src_out && dst_out && milli_out, "qrlsh_topk_fill: null pointer");
   QR_LAUNCH("topk_fill", (compact_fill_kernel<PRED_TOPK>), dim3((unsigned)ceil_div64(n_edges, CMP_TILE)),
                      dim3(CMP_THREADS), 0, static_cast<hipStream_t>(stream), sorted_edges, n_edges, K, id_bits + 11,
-                     id_bits, static_cast<const uint64_t *>(workspace), nullptr, src_out, dst_out, milli_out);
+                     id_bits, sorted_dst, static_cast<const uint64_t *>(workspace), nullptr, src_out, dst_out, milli_out);
   QR_LAUNCH_CHECK("qrlsh_topk_fill");
   return QRLSH_OK;
 }

@@ -27,7 +27,8 @@ __global__ __launch_bounds__(256) void score_pairs_kernel(const SigT *__restrict
                                                           const int64_t *__restrict__ norm2, int P,
                                                           const uint64_t *__restrict__ pairs, int64_t n,
                                                           int32_t *__restrict__ milli, double *__restrict__ cosv,
-                                                          uint64_t *__restrict__ edges, int id_bits) {
+                                                          uint64_t *__restrict__ edges, int id_bits,
+                                                          uint32_t *__restrict__ edge_dst) {
   constexpr bool IS16 = sizeof(SigT) == 2;
   constexpr int VEC = IS16 ? 8 : 4;
   const int lane = threadIdx.x & (WAVE - 1);
@@ -81,8 +82,15 @@ __global__ __launch_bounds__(256) void score_pairs_kernel(const SigT *__restrict
       if (cosv) cosv[t] = cs;
       if (edges) {
         const uint64_t inv = (uint64_t)(1000 - mi);
-        edges[2 * t] = ((uint64_t)i << (id_bits + 11)) | (inv << id_bits) | j;
-        edges[2 * t + 1] = ((uint64_t)j << (id_bits + 11)) | (inv << id_bits) | i;
+        if (edge_dst) {  // wide ids: src << 11 | inv in the key, dst as the payload
+          edges[2 * t] = ((uint64_t)i << 11) | inv;
+          edges[2 * t + 1] = ((uint64_t)j << 11) | inv;
+          edge_dst[2 * t] = j;
+          edge_dst[2 * t + 1] = i;
+        } else {
+          edges[2 * t] = ((uint64_t)i << (id_bits + 11)) | (inv << id_bits) | j;
+          edges[2 * t + 1] = ((uint64_t)j << (id_bits + 11)) | (inv << id_bits) | i;
+        }
       }
     }
   }
@@ -90,12 +98,14 @@ __global__ __launch_bounds__(256) void score_pairs_kernel(const SigT *__restrict
 
 QRLSH_EXPORT int qrlsh_score_pairs(const void *sig, int32_t sig_dtype, const int64_t *norm2, int32_t P,
                                    const uint64_t *pairs, int64_t n, int32_t *milli_out, double *cos_out,
-                                   uint64_t *edge_out, int32_t id_bits, void *stream) {
+                                   uint64_t *edge_out, int32_t id_bits, uint32_t *edge_dst_out, void *stream) {
   QR_CHECK_ARG(n >= 0 && P > 0, "qrlsh_score_pairs: bad sizes n=%lld P=%d", (long long)n, P);
   QR_CHECK_ARG(sig_dtype == QRLSH_SIG_I32 || sig_dtype == QRLSH_SIG_U16, "qrlsh_score_pairs: bad sig_dtype %d", sig_dtype);
   if (n == 0) return QRLSH_OK;
   QR_CHECK_ARG(sig && norm2 && pairs && milli_out, "qrlsh_score_pairs: null pointer");
-  if (edge_out) QR_CHECK_ARG(id_bits > 0 && id_bits <= 26, "qrlsh_score_pairs: id_bits=%d must be in [1,26]", id_bits);
+  if (edge_out && !edge_dst_out)
+    QR_CHECK_ARG(id_bits > 0 && id_bits <= 26, "qrlsh_score_pairs: id_bits=%d must be in [1,26] without edge_dst_out", id_bits);
+  QR_CHECK_ARG(!edge_dst_out || edge_out, "qrlsh_score_pairs: edge_dst_out needs edge_out");
   const int64_t groups_per_block = 256 / SCORE_LPP;
   int64_t blocks = ceil_div64(n, groups_per_block);
   if (blocks > 256 * 32) blocks = 256 * 32;  // grid-stride beyond 32 workgroups per CU
@@ -106,18 +116,18 @@ QRLSH_EXPORT int qrlsh_score_pairs(const void *sig, int32_t sig_dtype, const int
     const uint16_t *s16 = static_cast<const uint16_t *>(sig);
     if (aligned && P % 8 == 0)
       QR_LAUNCH("score_pairs", (score_pairs_kernel<uint16_t, true>), grid, block, 0, st, s16, norm2, P, pairs, n, milli_out,
-                cos_out, edge_out, id_bits);
+                cos_out, edge_out, id_bits, edge_dst_out);
     else
       QR_LAUNCH("score_pairs", (score_pairs_kernel<uint16_t, false>), grid, block, 0, st, s16, norm2, P, pairs, n, milli_out,
-                cos_out, edge_out, id_bits);
+                cos_out, edge_out, id_bits, edge_dst_out);
   } else {
     const int32_t *s32 = static_cast<const int32_t *>(sig);
     if (aligned && P % 4 == 0)
       QR_LAUNCH("score_pairs", (score_pairs_kernel<int32_t, true>), grid, block, 0, st, s32, norm2, P, pairs, n, milli_out,
-                cos_out, edge_out, id_bits);
+                cos_out, edge_out, id_bits, edge_dst_out);
     else
       QR_LAUNCH("score_pairs", (score_pairs_kernel<int32_t, false>), grid, block, 0, st, s32, norm2, P, pairs, n, milli_out,
-                cos_out, edge_out, id_bits);
+                cos_out, edge_out, id_bits, edge_dst_out);
   }
   QR_LAUNCH_CHECK("qrlsh_score_pairs");
   return QRLSH_OK;

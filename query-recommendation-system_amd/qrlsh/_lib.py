@@ -50,9 +50,9 @@ SIGNATURES = {
     "qrlsh_unique_fill": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp]),
     "qrlsh_row_norms": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp]),
     "qrlsh_verify_pairs": (ctypes.c_int, [_vp, _i32, _i32, _i32, _vp, _i64, _vp, _vp]),
-    "qrlsh_score_pairs": (ctypes.c_int, [_vp, _i32, _vp, _i32, _vp, _i64, _vp, _vp, _vp, _i32, _vp]),
+    "qrlsh_score_pairs": (ctypes.c_int, [_vp, _i32, _vp, _i32, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp]),
     "qrlsh_topk_count": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _sz, _vp, _vp]),
-    "qrlsh_topk_fill": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "qrlsh_topk_fill": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "qrlsh_answer_sets_count": (ctypes.c_int, [_vp, _i64, _i64, _vp, _i64, _i32, _vp, _vp]),
     "qrlsh_answer_sets_fill": (ctypes.c_int, [_vp, _i64, _i64, _vp, _i64, _i32, _vp, _vp, _vp]),
     "qrlsh_prof_enable": (ctypes.c_int, [ctypes.c_int]),

@@ -52,9 +52,12 @@ class HipBackend:
     def verify(self, sig_all, b, pairs):
         return ops.drop_unverified(sig_all, b, pairs)
 
-    def score(self, sig_all, norm_all, pairs, id_bits):
-        milli, _, edges = ops.score_pairs(sig_all, norm_all, pairs, edge_id_bits=id_bits)
+    def score(self, sig_all, norm_all, pairs, id_bits, wide=False):
+        milli, _, edges = ops.score_pairs(sig_all, norm_all, pairs, edge_id_bits=id_bits, wide=wide)
         return milli, edges
+
+    def sort_words_kv(self, words, vals, lo, hi):
+        return ops.sort_u64(words, vals, lo, hi)
 
     def topk(self, edges, K, id_bits):
         return ops.topk_edges(edges, K, id_bits)
@@ -140,7 +143,7 @@ def _split_by_bounds(sorted_words, bounds):
 
 
 def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="all_to_all", backend=None,
-                               group=None):
+                               group=None, wide_ids=None):
     """Hot path for this rank's query shard; collective over `group`.  Every rank must hold
     the same number of queries (nq_total % world == 0).  Returns a HotPathResult whose pairs /
     top-K rows are this rank's share (global query ids); concatenated over ranks in rank
@@ -156,8 +159,7 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
         raise AssertionError("signature length %d not divisible by b=%d" % (P, b))
     r = P // b
     ib = ops.id_bits_for(nq_total)
-    if 2 * ib + 11 > 64:
-        raise NotImplementedError("nq_total=%d needs %d-bit ids; the top-K key holds 26" % (nq_total, ib))
+    wide = ops.wide_ids(ib) if wide_ids is None else wide_ids
     dev = offsets.device
     stats = {}
 
@@ -212,16 +214,28 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
     h_nrm.wait()
     if r > 4 and pairs.numel():   # wide bands: hashed bucket ids -> exact verification on the owner
         pairs = be.verify(sig_all, b, pairs)
-    milli, edges = be.score(sig_all, norm_all, pairs, ib)
-    fwd = edges[0::2].contiguous()
-    rev = be.sort_words(edges[1::2].contiguous(), ib + 11, 2 * ib + 11) if pairs.numel() else edges[1::2].contiguous()
-    ebounds = [(g * nql) << (ib + 11) for g in range(1, world)]
-    rev_in = _exchange_var(_split_by_bounds(rev, ebounds), rev, group)
+    milli, edges = be.score(sig_all, norm_all, pairs, ib, wide)
+    if wide:
+        # key + payload edges (src << 11 | inv, dst): ids of any width
+        ek, ed = edges
+        fwd_k, fwd_d = ek[0::2].contiguous(), ed[0::2].contiguous()
+        rev_k, rev_d = ek[1::2].contiguous(), ed[1::2].contiguous()
+        if pairs.numel():
+            rev_k, rev_d = be.sort_words_kv(rev_k, rev_d, 11, ib + 11)
+        sizes = _split_by_bounds(rev_k, [(g * nql) << 11 for g in range(1, world)])
+        rk_in = _exchange_var(sizes, rev_k, group)
+        rd_in = _exchange_var(sizes, rev_d.view(torch.int32), group)
+        edges_local = (torch.cat([rk_in, fwd_k]), torch.cat([rd_in, fwd_d]))
+    else:
+        fwd = edges[0::2].contiguous()
+        rev = be.sort_words(edges[1::2].contiguous(), ib + 11, 2 * ib + 11) if pairs.numel() else edges[1::2].contiguous()
+        ebounds = [(g * nql) << (ib + 11) for g in range(1, world)]
+        rev_in = _exchange_var(_split_by_bounds(rev, ebounds), rev, group)
+        edges_local = torch.cat([rev_in, fwd])
 
-    # 7. local top-K
-    # order matters for the stable top-K sort: per src, reverse edges (dst < src, ascending by
-    # sender rank and pair order) come before forward edges (dst > src, ascending)
-    src, dst, val = be.topk(torch.cat([rev_in, fwd]), K, ib)
+    # 7. local top-K.  Order matters for the stable top-K sort: per src, reverse edges (dst < src,
+    # ascending by sender rank and pair order) come before forward edges (dst > src, ascending)
+    src, dst, val = be.topk(edges_local, K, ib)
     stats["unique_pairs"] = int(pairs.numel())
     stats["kept_edges"] = int(src.numel())
     return HotPathResult(sig, norm2, pairs, milli, src, dst, val, K, b, stats)

@@ -350,10 +350,16 @@ def candidate_pairs(keys, r, stats=None, sig=None):
 # ---------------------------------------------------------------------------
 # a5: scoring and top-K
 # ---------------------------------------------------------------------------
-def score_pairs(sig, norm2, pairs, want_cos=False, edge_id_bits=None):
+def wide_ids(id_bits):
+    """two ids + 11 score bits do not fit one 64-bit top-K key: use key + payload edges"""
+    return 2 * id_bits + 11 > 64
+
+
+def score_pairs(sig, norm2, pairs, want_cos=False, edge_id_bits=None, wide=None):
     """milli = rint(1000 * cosine(sig_i, sig_j)) per pair (recommender.py:203-204).  sig: int32
     rows or compact uint16 rows (torch.int16).
-    Returns (milli int32, cos float64 | None, edges int64 [2n] | None)."""
+    Returns (milli int32, cos float64 | None, edges | None); edges is the int64 [2n] packed key
+    tensor, or with wide ids (forced by wide=True) the tuple (keys int64 [2n], dst int32 [2n])."""
     lib = _lib.load()
     if not isinstance(sig, torch.Tensor) or sig.dtype not in (torch.int32, torch.int16):
         raise TypeError("sig must be an int32 or int16 (compact) tensor")
@@ -365,17 +371,24 @@ def score_pairs(sig, norm2, pairs, want_cos=False, edge_id_bits=None):
     milli = torch.empty((n,), dtype=torch.int32, device=dev)
     cosv = torch.empty((n,), dtype=torch.float64, device=dev) if want_cos else None
     edges = torch.empty((2 * n,), dtype=torch.int64, device=dev) if edge_id_bits is not None else None
+    if wide is None:
+        wide = edge_id_bits is not None and wide_ids(edge_id_bits)
+    edst = torch.empty((2 * n,), dtype=torch.int32, device=dev) if (wide and edges is not None) else None
     code = _lib.SIG_U16 if sig.dtype == torch.int16 else _lib.SIG_I32
     _lib.check(lib.qrlsh_score_pairs(_ptr(sig), code, _ptr(norm2), sig.shape[1], _ptr(pairs), n, _ptr(milli),
                                      _ptr(cosv), _ptr(edges), edge_id_bits if edge_id_bits is not None else 0,
-                                     _stream()))
-    return milli, cosv, edges
+                                     _ptr(edst), _stream()))
+    return milli, cosv, ((edges, edst) if edst is not None else edges)
 
 
 def topk_edges(edges, K, id_bits):
-    """Per-query top-K (recommender.py:206-210) from the directed edge keys written by
-    score_pairs: -> (src, dst, milli) int32, sorted by src, value desc, dst asc; <= K per src."""
+    """Per-query top-K (recommender.py:206-210) from the directed edges written by score_pairs
+    (packed int64 keys, or the (keys, dst) tuple of the wide-id format):
+    -> (src, dst, milli) int32, sorted by src, value desc, dst asc; <= K per src."""
     lib = _lib.load()
+    edst = None
+    if isinstance(edges, tuple):
+        edges, edst = edges
     _need(edges, torch.int64, "edges", 1)
     dev = edges.device
     n = edges.numel()
@@ -385,15 +398,20 @@ def topk_edges(edges, K, id_bits):
     # Sorting on (src, 1000-milli) alone is enough: the sort is stable and, per src, the edges
     # arrive with dst ascending (pairs are sorted by (i, j); edge 2t is i->j, 2t+1 is j->i, so a
     # src first meets its smaller neighbours, then its larger ones) -- 4 passes instead of 7.
-    se, _ = sort_u64(edges, None, id_bits, 2 * id_bits + 11)
+    if edst is None:
+        se, sd = sort_u64(edges, None, id_bits, 2 * id_bits + 11)
+        kb = id_bits
+    else:
+        se, sd = sort_u64(edges, edst, 0, id_bits + 11)
+        kb = 0
     ws = _ws(lib.qrlsh_compact_workspace_bytes(n), dev)
     total = torch.zeros(1, dtype=torch.int64, device=dev)
-    _lib.check(lib.qrlsh_topk_count(_ptr(se), n, K, id_bits, _ptr(ws), ws.numel(), _ptr(total), _stream()))
+    _lib.check(lib.qrlsh_topk_count(_ptr(se), n, K, kb, _ptr(ws), ws.numel(), _ptr(total), _stream()))
     m = int(total.item())
     src = torch.empty((m,), dtype=torch.int32, device=dev)
     dst = torch.empty((m,), dtype=torch.int32, device=dev)
     val = torch.empty((m,), dtype=torch.int32, device=dev)
-    _lib.check(lib.qrlsh_topk_fill(_ptr(se), n, K, id_bits, _ptr(ws), _ptr(src), _ptr(dst), _ptr(val), _stream()))
+    _lib.check(lib.qrlsh_topk_fill(_ptr(se), _ptr(sd), n, K, kb, _ptr(ws), _ptr(src), _ptr(dst), _ptr(val), _stream()))
     return src, dst, val
 
 

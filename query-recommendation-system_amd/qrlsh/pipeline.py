@@ -51,7 +51,7 @@ class HotPathResult:
         return ops.sig_to_int32(self.sig)
 
 
-def query_similarities(offsets, rows, table, b, K, timings=None, compact=None):
+def query_similarities(offsets, rows, table, b, K, timings=None, compact=None, wide_ids=None):
     """Whole hot path for the queries described by (offsets, rows) on offsets.device.
 
     table: ops.PermTable (transposed permutations).  Returns HotPathResult; `timings`, when a
@@ -80,7 +80,7 @@ def query_similarities(offsets, rows, table, b, K, timings=None, compact=None):
     del keys
     t0 = tick("candidates", t0)
     ib = ops.id_bits_for(nq)
-    milli, _, edges = ops.score_pairs(sig, norm2, pairs, edge_id_bits=ib)
+    milli, _, edges = ops.score_pairs(sig, norm2, pairs, edge_id_bits=ib, wide=wide_ids)
     t0 = tick("scoring", t0)
     src, dst, val = ops.topk_edges(edges, K, ib)
     tick("topk", t0)

@@ -32,7 +32,17 @@ class OracleBackend:
 
     def minhash(self, offsets, rows, table, b):
         sig = O.minhash(offsets.numpy(), rows.numpy(), table.perms)
-        keys = O.band_keys(sig, b).T.copy()
+        P = sig.shape[1]
+        if P // b <= 4:
+            keys = O.band_keys(sig, b).T.copy()
+        else:   # wide bands: any 64-bit hash of the tuple will do for the test backend (FNV-1a)
+            lo = (sig.astype(np.int64) & 0xFFFF).astype(np.uint64).reshape(len(sig), b, P // b)
+            h = np.full((len(sig), b), 0xCBF29CE484222325, dtype=np.uint64)
+            with np.errstate(over="ignore"):
+                for t in range(P // b):
+                    h = (h ^ lo[:, :, t]) * np.uint64(0x100000001B3)
+            h[np.all(lo == 0xFFFF, axis=2)] = np.uint64(0xFFFFFFFFFFFFFFFF)
+            keys = h.T.copy()
         norm2 = (sig.astype(np.int64) ** 2).sum(1)
         return _t(sig), _t(norm2), _t(keys.view(np.int64))
 
@@ -65,19 +75,49 @@ class OracleBackend:
         d = (w >> np.uint64(lo)) & np.uint64((1 << (hi - lo)) - 1)
         return _t(w[np.argsort(d, kind="stable")].view(np.int64))
 
-    def score(self, sig_all, norm_all, pairs, id_bits):
+    def verify(self, sig_all, b, pairs):
+        p = pairs.numpy().view(np.uint64)
+        truth = O.candidates_from_sig(sig_all.numpy(), b)
+        return _t(p[np.isin(p, truth)].view(np.int64))
+
+    def score(self, sig_all, norm_all, pairs, id_bits, wide=False):
         p = pairs.numpy().view(np.uint64)
         milli = O.score_pairs(sig_all.numpy(), p, mode=1)
         i = p >> np.uint64(32)
         j = p & np.uint64(0xFFFFFFFF)
         inv = (1000 - milli).astype(np.uint64)
-        sh = np.uint64(id_bits + 11)
         e = np.empty(2 * len(p), dtype=np.uint64)
+        if wide:
+            e[0::2] = (i << np.uint64(11)) | inv
+            e[1::2] = (j << np.uint64(11)) | inv
+            d = np.empty(2 * len(p), dtype=np.int32)
+            d[0::2] = j.astype(np.int32)
+            d[1::2] = i.astype(np.int32)
+            return _t(milli), (_t(e.view(np.int64)), _t(d))
+        sh = np.uint64(id_bits + 11)
         e[0::2] = (i << sh) | (inv << np.uint64(id_bits)) | j
         e[1::2] = (j << sh) | (inv << np.uint64(id_bits)) | i
         return _t(milli), _t(e.view(np.int64))
 
+    def sort_words_kv(self, words, vals, lo, hi):
+        w = words.numpy().view(np.uint64)
+        d = (w >> np.uint64(lo)) & np.uint64((1 << (hi - lo)) - 1)
+        o = np.argsort(d, kind="stable")
+        return _t(w[o].view(np.int64)), _t(vals.numpy()[o])
+
     def topk(self, edges, K, id_bits):
+        if isinstance(edges, tuple):                       # wide ids: (src << 11 | inv, dst), input order = dst asc per src
+            k = edges[0].numpy().view(np.uint64)
+            dd = edges[1].numpy()
+            o = np.argsort(k, kind="stable")
+            k, dd = k[o], dd[o]
+            src = (k >> np.uint64(11)).astype(np.int64)
+            keep = np.ones(len(k), dtype=bool)
+            if len(k) > K:
+                keep[K:] = src[K:] != src[:-K]
+            k, dd = k[keep], dd[keep]
+            return (_t((k >> np.uint64(11)).astype(np.int32)), _t(dd.astype(np.int32)),
+                    _t((1000 - (k & np.uint64(0x7FF)).astype(np.int64)).astype(np.int32)))
         e = np.sort(edges.numpy().view(np.uint64))
         src = (e >> np.uint64(id_bits + 11)).astype(np.int64)
         keep = np.ones(len(e), dtype=bool)
@@ -92,6 +132,7 @@ class OracleBackend:
 
 def main():
     out_dir, nq, D, P, b, mode = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
+    wide = len(sys.argv) > 7 and sys.argv[7] == "wide"
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     nql = nq // world
@@ -99,7 +140,7 @@ def main():
     perms = O.legacy_permutations(42, P, D)
     off, rows = O.synth_csr(nq, D, seed=3, cluster=4, mean=6.0, q0=rank * nql, nq_local=nql)
     res = qdist.query_similarities_sharded(_t(off), _t(rows), OracleTable(perms), b, K, nq, exchange=mode,
-                                           backend=OracleBackend())
+                                           backend=OracleBackend(), wide_ids=wide or None)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), sig=res.sig.numpy(), pairs=res.pairs.numpy(),
              milli=res.milli.numpy(), src=res.src.numpy(), dst=res.dst.numpy(), val=res.val.numpy(),
              emitted=res.stats["emitted_pairs"])

@@ -490,3 +490,15 @@ def test_verify_pairs_is_the_exact_candidate_predicate():
         assert np.array_equal(flags, truth)
         kept = ops.drop_unverified(s_dev, b, dev(allp.view(np.int64)))
         assert np.array_equal(u64(kept), true_pairs)
+
+
+def test_wide_id_edge_format_gives_the_same_topk():
+    nq, D, P, b = 30000, 32768, 128, 32
+    K = pipeline.max_candidates(nq)
+    off, rows = qrlsh.synth_csr(nq, D, seed=0, device=DEV)
+    table = ops.perm_table(ops.legacy_permutations(P, D, seed=42), DEV)
+    a = pipeline.query_similarities(off, rows, table, b, K)
+    w = pipeline.query_similarities(off, rows, table, b, K, wide_ids=True)
+    torch.cuda.synchronize()
+    assert torch.equal(a.src, w.src) and torch.equal(a.dst, w.dst) and torch.equal(a.val, w.val)
+    assert not ops.wide_ids(26) and ops.wide_ids(27)
