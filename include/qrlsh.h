@@ -188,6 +188,20 @@ int qrlsh_answer_sets_fill(const uint32_t *bitmaps, int64_t words_per_row, int64
                            const int32_t *qrows, int64_t nq, int32_t nfeat, const int64_t *offsets,
                            int32_t *rows_out, void *stream);
 
+/* ---- N1: hybrid prediction loop (the consumer of the hot path's output) ---------------------
+ * Replaces the per-cell loop of Recommender.compute_scores, recommender.py:301-331, and
+ * weighted_average, recommender.py:36-47.  ratings int32 [nu][nq] (0 = missing).  Query
+ * neighbours in CSR form (q_off[nq+1], q_idx, q_val = rounded cosine, i.e. milli / 1000.0) as
+ * qrlsh_topk_* produce them; user neighbours padded [nu][ku] (u_idx = -1 past the end).
+ * out[nu][nq] = the utility matrix with every zero cell replaced by round(blend) (0 when neither
+ * side predicts).  float64 arithmetic in the reference's order (numpy pairwise sums, no FMA,
+ * round half to even).  ku <= 64 and at most 64 neighbours per query are used.
+ */
+int qrlsh_predict(const int32_t *ratings, int64_t nu, int64_t nq, const int64_t *q_off,
+                  const int32_t *q_idx, const double *q_val, const int32_t *u_idx, const double *u_val,
+                  int32_t ku, double query_weight, double user_weight, double default_mean,
+                  int32_t *out, void *stream);
+
 /* ---- synthetic answer sets (bench / test input) ---------------
  * Bit-identical twin of oracle/qr_oracle.c:qro_synth_*: a pure function of (seed, q).
  * sizes: sizes_out[i] = |A(q0 + i)|; fill: rows at offsets[i] (offsets = exclusive scan).

@@ -318,3 +318,104 @@ def pairs_to_u64(pairs_2col):
 def u64_to_pairs(p):
     p = np.asarray(p, dtype=np.uint64)
     return np.stack([(p >> np.uint64(32)).astype(np.int64), (p & np.uint64(0xFFFFFFFF)).astype(np.int64)], axis=1)
+
+
+# ---------------------------------------------------------------------------
+# N4 / N1: user similarity and the hybrid prediction loop (recommender.py:216-343)
+# ---------------------------------------------------------------------------
+QUERY_WEIGHT, USER_WEIGHT, DEFAULT_MEAN = 0.6, 0.4, 60   # recommender.py:32-34
+
+
+def user_similarities(ratings):
+    """recommender.py:216-290 restated: StandardScaler -> PCA(min(r, c, 200)) -> BIRCH with
+    round(nu ** (1/1.3)) clusters, singleton clusters pooled; per cluster the rows are centred on
+    their non-zero mean IN PLACE IN THE INTEGER ARRAY (the reference's np.array(self.ratings[...])
+    keeps the integer dtype, so the centred values are truncated toward zero), cosine, round to 3,
+    zero diagonal and negatives; per user the top K = round(log_1.5 nu) of its cluster row.
+    -> {u: {'indexes': int64[], 'values': float64[]}}"""
+    from sklearn.cluster import Birch
+    from sklearn.decomposition import PCA
+    from sklearn.metrics.pairwise import cosine_similarity
+    from sklearn.preprocessing import StandardScaler
+    ratings = np.asarray(ratings)
+    nu = ratings.shape[0]
+    K = round(math.log(nu, 1.5))
+    n_clusters = round(nu ** (1 / 1.3))
+    x = StandardScaler().fit_transform(ratings)
+    x = PCA(n_components=min(x.shape[0], x.shape[1], 200)).fit(x).transform(x)
+    labels = Birch(n_clusters=n_clusters).fit(x).predict(x)
+    counts = np.bincount(labels)
+    for c in range(counts.size):
+        if counts[c] == 1:
+            labels[labels == c] = n_clusters
+    out = {}
+    for c in np.unique(labels):
+        members = np.where(labels == c)[0]
+        block = np.array(ratings[members])            # integer dtype survives: truncation below is the reference's
+        for s in range(len(block)):
+            nz = block[s] != 0
+            block[s][nz] = block[s][nz] - np.mean(block[s][nz])
+        sim = np.around(cosine_similarity(block), 3)
+        np.fill_diagonal(sim, 0)
+        sim[sim < 0] = 0
+        for local, u in enumerate(members):
+            order = np.argsort(sim[local])[::-1][:K]
+            out[int(u)] = {"indexes": members[order].astype(np.int64), "values": sim[local][order]}
+    return out
+
+
+def np_sum_order(a):
+    """numpy's summation order for a contiguous float64 vector of <= 128 elements (pairwise_sum:
+    plain loop below 8, else 8 running sums combined as ((0+1)+(2+3))+((4+5)+(6+7)), tail added
+    one by one) -- what np.sum does inside weighted_average when numba's jit is the identity."""
+    n = len(a)
+    if n < 8:
+        r = 0.0
+        for v in a:
+            r += float(v)
+        return r
+    r = [float(a[k]) for k in range(8)]
+    i = 8
+    while i < n - (n % 8):
+        for k in range(8):
+            r[k] += float(a[i + k])
+        i += 8
+    res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]))
+    while i < n:
+        res += float(a[i])
+        i += 1
+    return res
+
+
+def weighted_average(ratings_row, indexes, values, summation=np_sum_order):
+    """recommender.py:36-47"""
+    if len(indexes) == 0:
+        return 0.0
+    ur = np.asarray(ratings_row)[np.asarray(indexes)]
+    vals = np.asarray(values, dtype=np.float64)
+    wsum = summation(vals[ur != 0])
+    if wsum == 0:
+        return 0.0
+    return summation(ur * vals) / wsum
+
+
+def predict_scores(ratings, query_sims, user_sims, summation=np_sum_order):
+    """The hybrid loop of compute_scores, recommender.py:301-331: every zero cell (i, j) gets
+    round(...) of the blend of the query-side and user-side weighted averages (Python round =
+    half to even).  -> int64 matrix like `finalPredictions`."""
+    ratings = np.asarray(ratings)
+    final = ratings.astype(np.int64).copy()
+    for i, j in np.array(np.where(ratings == 0)).T:
+        qp = 0.0
+        if int(j) in query_sims:
+            qp = weighted_average(ratings[i], query_sims[int(j)]["indexes"], query_sims[int(j)]["values"], summation)
+        up = weighted_average(ratings.T[j], user_sims[int(i)]["indexes"], user_sims[int(i)]["values"], summation)
+        if up == 0 and qp == 0:
+            final[i][j] = 0
+        elif up == 0:
+            final[i][j] = round(qp * (QUERY_WEIGHT + (USER_WEIGHT * 0.5)) + DEFAULT_MEAN * (USER_WEIGHT * 0.5))
+        elif qp == 0:
+            final[i][j] = round(up * (USER_WEIGHT + (QUERY_WEIGHT * 0.5)) + DEFAULT_MEAN * (QUERY_WEIGHT * 0.5))
+        else:
+            final[i][j] = round(qp * QUERY_WEIGHT + up * USER_WEIGHT)
+    return final

@@ -12,14 +12,16 @@ np.random.seed(s) the signatures are bit-identical to the reference's.  Tie orde
 query's top-K list is defined here (value descending, then neighbour id ascending); the
 reference's is arbitrary.
 
-Answer sets (compute_shingles) are built on the device too (qrlsh.answers).
-User similarity, the prediction loop, CSV ingest and the interactive prompt are outside this
-round's scope.
+Widening beyond the hot path: answer sets (compute_shingles, N2) and the
+hybrid prediction loop (compute_scores / weighted_average, N1) run on the device; CSV ingest
+(init / parse_queries, N3) uses pandas instead of datatable; user similarity (N4) is the same
+sklearn pipeline the reference calls, on the host.
 """
 import math
 import time
 
 import numpy as np
+import pandas as pd
 import torch
 
 import qrlsh
@@ -48,16 +50,34 @@ class Recommender:
             print(*a)
 
     def init(self, users, queries, queriesIDs, dataset, ratings):
-        """recommender.py:51-64 for pandas / numpy inputs (the datatable ingest is row N3)."""
+        """recommender.py:51-64 for pandas inputs (N3: no datatable): users = one-column frame of
+        user ids, queries = frame from parse_queries, dataset = the table, ratings = the utility
+        matrix frame with its leading 'user' column; missing ratings become 0."""
         def to_np(x):
             return x.to_numpy() if hasattr(x, "to_numpy") else np.asarray(x)
         self.usersIDs = to_np(users).T[0]
         self.queries = to_np(queries)
         self.queriesIDs = np.array(queriesIDs)
-        self.dataset = dataset.astype(str) if hasattr(dataset, "astype") else dataset
+        self.dataset = dataset.astype(str)
         self.tupleCount = {}
-        r = ratings.drop(columns=["user"]) if hasattr(ratings, "drop") and "user" in getattr(ratings, "columns", []) else ratings
-        self.ratings = np.nan_to_num(to_np(r).astype(float), nan=0.0)
+        if hasattr(ratings, "columns") and "user" in ratings.columns:
+            ratings = ratings.drop(columns=["user"])
+        self.ratings = np.nan_to_num(to_np(ratings).astype(np.float64), nan=0.0).astype(np.int64)
+
+    def parse_queries(self, path: str):
+        """recommender.py:386-416: one query per line, `id,attr=value,attr=value,...`;
+        -> (DataFrame with one column per dataset feature, "" where unconstrained; list of ids)"""
+        ids, data = [], []
+        with open(path) as fh:
+            for line in fh:
+                parts = line.rstrip("\n").split(",")
+                ids.append(parts[0])
+                row = ["" for _ in self.datasetFeatures]
+                for item in parts[1:]:
+                    name, value = item.split("=")
+                    row[self.datasetFeatures.index(name)] = value
+                data.append(row)
+        return pd.DataFrame(data, columns=list(self.datasetFeatures), dtype=object), ids
 
     # ---- producer of the hot path's input (row N2: answer sets on the device) -----
     def answer_sets_device(self):
@@ -142,3 +162,84 @@ class Recommender:
         query_sim = pipeline.sims_to_dict(res.src, res.dst, res.val)
         self._log("\n" + str(round(time.time() - queryTime, 3)) + "s for overall queries_similarity scores")
         return query_sim
+
+    # ---- N4: user similarity (host; the reference's own sklearn pipeline) -----------
+    def compute_userSimilarities(self):
+        """{u: {'indexes', 'values'}} (recommender.py:216-290): StandardScaler -> PCA -> BIRCH, then
+        centred cosine inside each cluster, top round(log_1.5 nu) per user."""
+        from sklearn.cluster import Birch
+        from sklearn.decomposition import PCA
+        from sklearn.metrics.pairwise import cosine_similarity
+        from sklearn.preprocessing import StandardScaler
+        t0 = time.time()
+        nu = self.usersIDs.size
+        top = round(math.log(nu, 1.5))
+        n_clusters = round(nu ** (1 / 1.3))
+        self._log("\nMax user candidates: {}, Total users: {}".format(top, nu))
+        feats = StandardScaler().fit_transform(self.ratings)
+        feats = PCA(n_components=min(feats.shape[0], feats.shape[1], 200)).fit(feats).transform(feats)
+        self._log("\nCluster count: {}, Total users: {}".format(n_clusters, nu))
+        label = Birch(n_clusters=n_clusters).fit(feats).predict(feats)
+        sizes = np.bincount(label)
+        label[np.isin(label, np.flatnonzero(sizes == 1))] = n_clusters     # pool the singletons (:259-261)
+        user_sim = {}
+        for c in np.unique(label):
+            members = np.flatnonzero(label == c)
+            # the reference centres the rows inside an INTEGER copy of the ratings (:268-272):
+            # the centred values are truncated toward zero, and parity needs the same
+            rows = self.ratings[members].astype(self.ratings.dtype, copy=True)
+            for k in range(rows.shape[0]):
+                rated = rows[k] != 0
+                rows[k][rated] = rows[k][rated] - np.mean(rows[k][rated])
+            sim = np.around(cosine_similarity(rows), 3)
+            np.fill_diagonal(sim, 0)
+            sim[sim < 0] = 0
+            for local, u in enumerate(members):
+                best = np.argsort(sim[local])[::-1][:top]
+                user_sim[int(u)] = {"indexes": members[best], "values": sim[local][best]}
+        self._log("\n" + str(round(time.time() - t0, 3)) + "s for overall users_similarity scores")
+        return user_sim
+
+    # ---- N1: hybrid prediction (device) ------------------------------------------------
+    def compute_scores(self):
+        """(scores_to_predict, finalPredictions DataFrame, scores_missed), recommender.py:292-343."""
+        from qrlsh import predict
+        self._log("\n========== QUERY SIMILARITY ==========")
+        self.compute_querySimilarities()
+        res = self.last_result
+        self._log("\n========== USER SIMILARITY ==========")
+        user_sim = self.compute_userSimilarities()
+        self._log("\n========== WEIGHTED AVERAGES ==========")
+        t0 = time.time()
+        scores_to_predict = np.array(np.where(self.ratings == 0)).T
+        final = predict.fill_predictions(self.ratings, res.src, res.dst, res.val, user_sim, QUERY_WEIGHT, USER_WEIGHT,
+                                         DEFAULT_MEAN, self.device)
+        final = final.cpu().numpy()
+        self._log(str(round(time.time() - t0, 3)) + "s for weighted averages")
+        finalPredictions = pd.DataFrame(final, columns=self.queriesIDs, index=self.usersIDs).astype(int)
+        scores_missed = np.array(np.where(finalPredictions == 0)).T
+        return scores_to_predict, finalPredictions, scores_missed
+
+    def top_k_queries(self, to_predict, predictions, missed, ask=input):
+        """Interactive top-k prompt of recommender.py:345-381 (`ask` is injectable for tests)."""
+        pred = predictions.to_numpy()
+        nu = self.usersIDs.size
+        again = ""
+        while again.lower() != "no":
+            user = -1
+            while not (0 <= user < nu):
+                txt = ask("Enter user ID: [int][Max: " + str(nu) + "] ")
+                user = int(txt) - 1 if txt.isdigit() else -1
+            fresh = [j for i, j in to_predict if i == user and pred[i][j] != 0]
+            k = 0
+            while not (0 < k <= len(fresh)):
+                txt = ask("Enter number of recommendations: [int][Max: " + str(len(fresh)) + "] ")
+                k = int(txt) if txt.isdigit() else 0
+            order = np.argsort(pred[user][fresh])[::-1][:k]
+            print("\nTop {} unrated query recommendations for U{}: ".format(k, user + 1))
+            for rank, pos in enumerate(order):
+                print("{}. Q{} - {}".format(rank + 1, fresh[pos] + 1, pred[user][fresh][pos]))
+            print()
+            again = ""
+            while again.lower() not in ("yes", "no"):
+                again = ask("Do you want more suggestions? [Yes-No][Default: Yes] ") or "yes"

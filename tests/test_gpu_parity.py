@@ -502,3 +502,57 @@ def test_wide_id_edge_format_gives_the_same_topk():
     torch.cuda.synchronize()
     assert torch.equal(a.src, w.src) and torch.equal(a.dst, w.dst) and torch.equal(a.val, w.val)
     assert not ops.wide_ids(26) and ops.wide_ids(27)
+
+
+# ---------------------------------------------------------------------------- N1 / N3 / N4
+def test_compute_scores_dropin_matches_reference_on_generator_default_inputs():
+    """main.py's flow on the generator-default CSVs through the drop-in Recommender: pandas
+    ingest (N3), device answer sets (N2), hot path, sklearn user similarity (N4), device
+    prediction loop (N1) -> the reference's finalPredictions, cell for cell."""
+    import pandas as pd
+    import recommender as R
+    g = load("cfg1_scores")
+    gdir = os.path.join(GOLDEN, "cfg1")
+    rec = R.Recommender()
+    rec.verbose = False
+    dataset = pd.read_csv(os.path.join(gdir, "dataset.csv"))
+    rec.datasetFeatures = list(dataset.columns)[1:]
+    users = pd.read_csv(os.path.join(gdir, "users.csv"), header=None)
+    queries, qids = rec.parse_queries(os.path.join(gdir, "queries.csv"))
+    ratings = pd.read_csv(os.path.join(gdir, "utility_matrix.csv"))
+    ratings.insert(0, "user", users[0].to_numpy())
+    ratings.columns = ["user"] + qids                      # main.py:70: cols = ["user"] + queriesIDs
+    rec.init(users, queries, qids, dataset, ratings)
+    assert np.array_equal(rec.ratings, g["ratings"])
+    R.PERM = int(g["P"])
+    np.random.seed(int(g["seed"]))
+    to_predict, final, missed = rec.compute_scores()
+    assert list(final.columns) == qids and list(final.index) == users[0].tolist()
+    assert np.array_equal(final.to_numpy(), g["final"])
+    assert np.array_equal(to_predict, g["to_predict"]) and np.array_equal(missed, g["missed"])
+    answers = iter(["abc", "3", "0", "2", "no"])
+    rec.top_k_queries(to_predict, final, missed, ask=lambda prompt: next(answers))
+
+
+def test_prediction_kernel_equals_oracle_on_random_inputs():
+    from qrlsh import predict
+    rng = np.random.default_rng(12)
+    for (nu, nq, Kq, Ku, fill) in [(7, 9, 3, 2, 0.5), (40, 60, 17, 11, 0.3), (25, 30, 20, 12, 0.8), (5, 5, 1, 1, 0.0)]:
+        ratings = (rng.integers(1, 101, size=(nu, nq)) * (rng.random((nu, nq)) < fill)).astype(np.int64)
+        qs, src, dst, mil = {}, [], [], []
+        for j in range(nq):
+            if rng.random() < 0.8:
+                n = int(rng.integers(1, Kq + 1))
+                idx = rng.choice(nq, size=min(n, nq), replace=False)
+                v = np.sort(rng.integers(0, 1001, size=len(idx)))[::-1]
+                qs[j] = {"indexes": idx.astype(np.int64), "values": v / 1000.0}
+                src += [j] * len(idx); dst += idx.tolist(); mil += v.tolist()
+        us = {}
+        for u in range(nu):
+            n = int(rng.integers(1, Ku + 1))
+            idx = rng.choice(nu, size=min(n, nu), replace=False)
+            us[u] = {"indexes": idx.astype(np.int64), "values": np.sort(rng.integers(0, 1001, size=len(idx)))[::-1] / 1000.0}
+        ref = O.predict_scores(ratings, qs, us)
+        out = predict.fill_predictions(ratings, torch.tensor(src, dtype=torch.int32), torch.tensor(dst, dtype=torch.int32),
+                                       torch.tensor(mil, dtype=torch.int32), us, device=DEV)
+        assert np.array_equal(out.cpu().numpy(), ref)

@@ -137,3 +137,24 @@ def test_answer_sets_match_reference_compute_shingles():
     cols, queries = _cfg1_table_and_queries()
     off, rows = O.answer_sets(cols, queries)
     assert np.array_equal(off, g["offsets"]) and np.array_equal(rows, g["rows"])
+
+
+def test_user_similarity_and_prediction_loop_match_reference():
+    """N4 + N1: restated compute_userSimilarities / compute_scores against the reference's own
+    outputs on the generator-default CSVs (tests/golden/cfg1_scores.npz)."""
+    g, h = load("cfg1_scores"), load("cfg1_hotpath")
+    us = O.user_similarities(g["ratings"])
+    for u in range(len(g["ratings"])):
+        n = int((g["us_idx"][u] >= 0).sum())
+        assert np.array_equal(us[u]["values"], g["us_val"][u][:n])            # values exact; tie order is arbitrary
+        nz = g["us_val"][u][:n] > 0
+        assert sorted(us[u]["indexes"][nz].tolist()) == sorted(g["us_idx"][u][:n][nz].tolist())
+    r = O.query_similarities(h["offsets"], h["rows"], int(h["D"]), int(h["P"]), int(h["b"]), int(h["K"]), int(h["seed"]))
+    qs = O.sims_to_dict(r["src"], r["dst"], r["val"])
+    final = O.predict_scores(g["ratings"], qs, us)
+    assert np.array_equal(final, g["final"])
+    assert np.array_equal(np.array(np.where(g["ratings"] == 0)).T, g["to_predict"])
+    assert np.array_equal(np.array(np.where(final == 0)).T, g["missed"])
+    # numba's sequential np.sum (the real reference) and numpy's pairwise order agree here
+    seq = O.predict_scores(g["ratings"], qs, us, summation=lambda a: float(sum(float(x) for x in a)))
+    assert np.array_equal(seq, g["final"])

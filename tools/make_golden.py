@@ -19,7 +19,7 @@ How the reference is run:
 
 Usage:  python tools/make_golden.py            (rewrites the round-1 base fixtures)
         python tools/make_golden.py NAME...    (only the named later additions: full_p100_r5,
-                                                full_p50_r5_wrap, pieces_p96_b12)
+                                                full_p50_r5_wrap, pieces_p96_b12, cfg1_scores)
 """
 import os
 import sys
@@ -312,6 +312,58 @@ def fixture_generator_default(recommender_mod, lsh_mod):
     print("cfg1: D=%d nq=%d P=%d b=%d K=%d pairs=%d sims=%d" % (D, nq, P, b, K, len(pairs), len(qids_a)))
 
 
+def fixture_cfg1_scores(recommender_mod, lsh_mod):
+    """config 1 through the reference's whole compute_scores (query + user similarity + hybrid
+    prediction loop, recommender.py:216-343) on the committed generator-default CSVs."""
+    gdir = os.path.join(OUT, "cfg1")
+    dataset = pd.read_csv(os.path.join(gdir, "dataset.csv"), dtype=str)
+    feats = list(dataset.columns)[1:]
+    qrows, qids = [], []
+    with open(os.path.join(gdir, "queries.csv")) as fh:
+        for line in fh:
+            vals = line.rstrip("\n").split(",")
+            qids.append(vals[0])
+            el = ["" for _ in feats]
+            for v in vals[1:]:
+                a = v.split("=")
+                el[feats.index(a[0])] = a[1]
+            qrows.append(el)
+    users = pd.read_csv(os.path.join(gdir, "users.csv"), header=None)
+    um = pd.read_csv(os.path.join(gdir, "utility_matrix.csv"))
+    ratings = um.fillna(0).to_numpy().astype(np.int64)      # what Recommender.init leaves (NaN -> 0, :61-64)
+    rec = recommender_mod.Recommender()
+    rec.datasetFeatures = feats
+    rec.dataset = dataset
+    rec.queries = np.array(qrows, dtype=object)
+    rec.queriesIDs = np.array(qids)
+    rec.usersIDs = users.to_numpy().T[0]
+    rec.ratings = ratings
+    rec.tupleCount = {}
+    recommender_mod.PERM = 180
+    seed = 42
+    _fresh_lsh_state(lsh_mod)
+    np.random.seed(seed)
+    with _quiet():
+        us = rec.compute_userSimilarities()
+    _fresh_lsh_state(lsh_mod)
+    np.random.seed(seed)
+    with _quiet():
+        to_predict, final, missed = rec.compute_scores()
+    _fresh_lsh_state(lsh_mod)
+    nu = len(rec.usersIDs)
+    K = max(len(us[u]["indexes"]) for u in us)
+    us_idx = np.full((nu, K), -1, dtype=np.int64)
+    us_val = np.zeros((nu, K), dtype=np.float64)
+    for u in range(nu):
+        n = len(us[u]["indexes"])
+        us_idx[u, :n] = us[u]["indexes"]
+        us_val[u, :n] = us[u]["values"]
+    np.savez_compressed(os.path.join(OUT, "cfg1_scores.npz"), seed=seed, P=180, ratings=ratings,
+                        us_idx=us_idx, us_val=us_val, final=final.to_numpy().astype(np.int64),
+                        to_predict=np.asarray(to_predict, dtype=np.int64), missed=np.asarray(missed, dtype=np.int64))
+    print("cfg1_scores: users=%d queries=%d to_predict=%d missed=%d" % (nu, len(qids), len(to_predict), len(missed)))
+
+
 def fixture_full(recommender_mod, lsh_mod, name, nq, D, P, seed, data_seed, **kw):
     offsets, rows = synth_csr(nq, D, data_seed, **kw)
     sig = run_signatures(recommender_mod, offsets, rows, D, P, seed)
@@ -400,6 +452,8 @@ def main():
         if want("full_p50_r5_wrap"):
             fixture_full(recommender_mod, lsh_mod, "full_p50_r5_wrap", nq=400, D=90000, P=50, seed=23, data_seed=9,
                          n_empty=2, n_dup=3, cluster=6, mean=8)
+        if want("cfg1_scores"):
+            fixture_cfg1_scores(recommender_mod, lsh_mod)
         if want("pieces_p96_b12"):
             fixture_pieces(recommender_mod, lsh_mod, "pieces_p96_b12", nq=500, D=3000, P=96, b=12, seed=29,
                            data_seed=10, n_empty=3, n_dup=3, p_replace=0.05)
