@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="queries in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="OpenMP threads of the CPU baseline (box share: 16/GPU)")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--exchange", default="all_to_all", choices=["all_to_all", "all_gather"],
+                    help="bucket-id exchange of the sharded path (N > 1)")
+    ap.add_argument("--force-dist", action="store_true", help="run the sharded driver even with one rank (testing)")
     return ap.parse_args()
 
 
@@ -92,6 +95,12 @@ def load_traffic():
 
 def main():
     args = parse()
+    # RCCL (and other native libraries) print banners on fd 1 when a communicator comes up; the
+    # contract is ONE JSON line on stdout, so everything else is sent to stderr for the whole run
+    # and the JSON goes to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -101,10 +110,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29544")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     import qrlsh
     from qrlsh import ops, pipeline, _lib
@@ -119,14 +130,14 @@ def main():
     table = ops.perm_table(perms, dev)
     nnz = int(rows.numel())
 
-    if world == 1:
+    if world == 1 and not args.force_dist:
         def step():
             return pipeline.query_similarities(off, rows, table, b, K)
     else:
         from qrlsh import dist as qdist
 
         def step():
-            return qdist.query_similarities_sharded(off, rows, table, b, K, nq_total)
+            return qdist.query_similarities_sharded(off, rows, table, b, K, nq_total, exchange=args.exchange)
 
     def sync():
         if dist is not None:
@@ -212,7 +223,8 @@ def main():
             "data": "synthetic (clustered answer sets, SURVEY 8d recipe; seed 0; permutation seed 42)",
             "config": {"workload": "configs[1]: %d queries/GPU x %d-perm MinHash, %d bands, D=%d, K=%d, mean |A(q)|=%.2f"
                        % (nq_local, P, b, D, K, nnz / nq_local),
-                       "queries_total": nq_total, "parallelism": "query-sharded x%d" % world},
+                       "queries_total": nq_total, "parallelism": "query-sharded x%d" % world,
+                       "bucket_id_exchange": (args.exchange if (world > 1 or args.force_dist) else "none (one GPU)")},
             "pairs_scored_per_sec": round(unique_pairs * args.steps / elapsed, 1),
             "unique_pairs": unique_pairs,
             "emitted_pairs": emitted,
@@ -226,7 +238,9 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if out is not None:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
 
 
 def cpu_leg(nq_s, D, P, b, dev, threads):

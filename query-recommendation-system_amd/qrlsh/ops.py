@@ -413,8 +413,3 @@ def topk_edges(edges, K, id_bits):
     val = torch.empty((m,), dtype=torch.int32, device=dev)
     _lib.check(lib.qrlsh_topk_fill(_ptr(se), _ptr(sd), n, K, kb, _ptr(ws), _ptr(src), _ptr(dst), _ptr(val), _stream()))
     return src, dst, val
-
-
-def max_candidates(nq):
-    """K = round(log_1.5 nq), recommender.py:151"""
-    return round(math.log(nq, 1.5))
