@@ -43,8 +43,10 @@ extern "C" {
 
 #define QRLSH_SORT_MIX 1u  /* radix digits are taken from mix64(key) (grouping sort) */
 #define QRLSH_SORT_IOTA 2u /* first pass synthesises vals = index within the batch */
-#define QRLSH_SORT_FOLD 4u /* digits from (key >> 32) << w | (key & (2^w - 1)), w = (flags >> 8) & 0xFF:
+#define QRLSH_SORT_FOLD 4u /* digits from (key >> 32) << w | (key & (2^w - 1)), w = aux:
                               sorts pairs i << 32 | j over [0, 2w) in ceil(2w / 8) passes */
+#define QRLSH_SORT_OWNER 8u /* ONE pass whose digit is (key >> bit_lo) / aux: groups words by the rank
+                               that owns the id starting at bit_lo (shards of aux ids, <= 256 ranks) */
 
 int qrlsh_version(void);
 const char *qrlsh_last_error(void);
@@ -91,8 +93,13 @@ int qrlsh_band_keys(const int32_t *sig, int64_t nq, int32_t P, int32_t b, uint64
  */
 size_t qrlsh_sort_workspace_bytes(int64_t n, int32_t nbatch);
 int qrlsh_sort_u64(uint64_t *keys_a, uint64_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, int64_t n,
-                   int32_t nbatch, int32_t bit_lo, int32_t bit_hi, uint32_t flags, void *workspace,
-                   size_t workspace_bytes, void *stream);
+                   int32_t nbatch, int32_t bit_lo, int32_t bit_hi, uint32_t flags, uint64_t aux,
+                   void *workspace, size_t workspace_bytes, void *stream);
+
+/* split points of words grouped with QRLSH_SORT_OWNER: bounds_out[g] (device int64 [world+1]) = first
+ * position whose owner (word >> bit_lo) / shard is >= g */
+int qrlsh_owner_bounds(const uint64_t *words, int64_t n, int32_t bit_lo, uint64_t shard, int32_t world,
+                       int64_t *bounds_out, void *stream);
 
 /* ---- a3: candidate pairs -------------------------------------------------------
  * Replaces LSH.get_candidates, lsh.py:40-55.  Input: per band, keys sorted with

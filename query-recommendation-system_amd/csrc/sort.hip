@@ -30,8 +30,14 @@ __device__ static inline int xcd_tile(int bid, int ntiles) {
 // digit source: MODE 0 = the key itself, 1 = mix64(key) (grouping sort), 2 = the key with its
 // two 32-bit halves packed next to each other, hi << fold | lo (pairs i << 32 | j sort in
 // ceil(2*id_bits / 8) passes instead of 2 * ceil(id_bits / 8)).
-enum { SM_PLAIN = 0, SM_MIX = 1, SM_FOLD = 2 };
-template <int MODE> __device__ static inline uint32_t digit_of(uint64_t key, int shift, int fold = 0) {
+// 3 = owner: (key >> shift) / aux, one pass that groups words by the rank owning the id field
+// (contiguous shards of aux ids each; at most 256 ranks).
+enum { SM_PLAIN = 0, SM_MIX = 1, SM_FOLD = 2, SM_OWNER = 3 };
+template <int MODE> __device__ static inline uint32_t digit_of(uint64_t key, int shift, uint32_t fold = 0) {
+  if (MODE == SM_OWNER) {
+    const uint64_t o = (key >> shift) / fold;
+    return o < RADIX ? (uint32_t)o : RADIX - 1;
+  }
   uint64_t x = key;
   if (MODE == SM_MIX) x = qr_mix64(key);
   if (MODE == SM_FOLD) x = ((key >> 32) << fold) | (key & ((1ull << fold) - 1ull));
@@ -52,7 +58,7 @@ template <int MIX, bool SPREAD = false>
 __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const uint64_t *__restrict__ keys, int64_t n,
                                                                  int ntiles, int shift,
                                                                  uint32_t *__restrict__ ghist, uint64_t ek = 0,
-                                                                 int fold = 0, uint32_t dmask = RADIX - 1,
+                                                                 uint32_t fold = 0, uint32_t dmask = RADIX - 1,
                                                                  const uint32_t *__restrict__ vals = nullptr) {
   __shared__ uint32_t h[RADIX];
   const int tile = blockIdx.x, batch = blockIdx.y;
@@ -64,6 +70,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const uint64_t 
 #pragma unroll
   for (int i = 0; i < SORT_IPT; ++i) {
     const int64_t idx = base + (int64_t)i * SORT_THREADS + threadIdx.x;
+    uint32_t dd = 0;
     if (idx < n) {
       const uint64_t key = k[idx];
       uint32_t d;
@@ -71,7 +78,21 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const uint64_t 
         d = part_digit<SPREAD>(key, (key == ek && v) ? (int64_t)v[idx] : idx, shift, ek, dmask);
       else
         d = digit_of<MIX>(key, shift, fold);
-      atomicAdd(&h[d], 1u);
+      if (MIX != SM_OWNER) atomicAdd(&h[d], 1u);
+      dd = d;
+    }
+    if (MIX == SM_OWNER) {
+      // a handful of distinct digits (ranks): one LDS atomic per digit per wave, not per key
+      const bool valid = idx < n;
+      uint64_t m = __ballot(valid);
+#pragma unroll
+      for (int bit = 0; bit < 8; ++bit) {
+        const bool one = (dd >> bit) & 1u;
+        const uint64_t bal = __ballot(one);
+        m &= one ? bal : ~bal;
+      }
+      const int lane = threadIdx.x & (WAVE - 1);
+      if (valid && (m & ((1ull << lane) - 1ull)) == 0) atomicAdd(&h[dd], (uint32_t)__popcll(m));
     }
   }
   __syncthreads();
@@ -121,7 +142,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const uint64
                                                                     int ntiles, int shift,
                                                                     const uint32_t *__restrict__ goff,
                                                                     const uint32_t *__restrict__ rtot,
-                                                                    uint64_t ek = 0, int fold = 0,
+                                                                    uint64_t ek = 0, uint32_t fold = 0,
                                                                     uint32_t dmask = RADIX - 1) {
   __shared__ uint32_t cnt[SORT_THREADS / WAVE][RADIX];
   __shared__ uint32_t dsum[SORT_THREADS / WAVE];
@@ -213,7 +234,7 @@ QRLSH_EXPORT size_t qrlsh_sort_workspace_bytes(int64_t n, int32_t nbatch) {
 
 template <int MIX>
 static int sort_passes(uint64_t *ka, uint64_t *kb, uint32_t *va, uint32_t *vb, int64_t n, int nbatch, int bit_lo,
-                       int bit_hi, bool iota, int fold, uint32_t *ghist, hipStream_t st) {
+                       int bit_hi, bool iota, uint32_t fold, uint32_t *ghist, hipStream_t st) {
   const int ntiles = (int)ceil_div64(n, SORT_TILE);
   const dim3 grid(ntiles, nbatch), block(SORT_THREADS);
   const bool has_val = va != nullptr;
@@ -244,8 +265,8 @@ static int sort_passes(uint64_t *ka, uint64_t *kb, uint32_t *va, uint32_t *vb, i
 }
 
 QRLSH_EXPORT int qrlsh_sort_u64(uint64_t *keys_a, uint64_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, int64_t n,
-                                int32_t nbatch, int32_t bit_lo, int32_t bit_hi, uint32_t flags, void *workspace,
-                                size_t workspace_bytes, void *stream) {
+                                int32_t nbatch, int32_t bit_lo, int32_t bit_hi, uint32_t flags, uint64_t aux,
+                                void *workspace, size_t workspace_bytes, void *stream) {
   QR_CHECK_ARG(n >= 0 && nbatch > 0, "qrlsh_sort_u64: bad sizes n=%lld nbatch=%d", (long long)n, nbatch);
   QR_CHECK_ARG(n < (1ll << 32), "qrlsh_sort_u64: n=%lld per batch exceeds 2^32-1", (long long)n);
   QR_CHECK_ARG(bit_lo >= 0 && bit_hi <= 64 && bit_lo <= bit_hi, "qrlsh_sort_u64: bad bit range [%d,%d)", bit_lo,
@@ -265,11 +286,43 @@ QRLSH_EXPORT int qrlsh_sort_u64(uint64_t *keys_a, uint64_t *keys_b, uint32_t *va
   if (flags & QRLSH_SORT_MIX)
     return sort_passes<SM_MIX>(keys_a, keys_b, vals_a, vals_b, n, nbatch, bit_lo, bit_hi, iota, 0, ghist, st);
   if (flags & QRLSH_SORT_FOLD) {
-    const int fold = (int)((flags >> 8) & 0xFF);
-    QR_CHECK_ARG(fold >= 1 && fold <= 32, "qrlsh_sort_u64: fold width %d not in [1,32]", fold);
-    return sort_passes<SM_FOLD>(keys_a, keys_b, vals_a, vals_b, n, nbatch, bit_lo, bit_hi, iota, fold, ghist, st);
+    QR_CHECK_ARG(aux >= 1 && aux <= 32, "qrlsh_sort_u64: fold width %llu not in [1,32]", (unsigned long long)aux);
+    return sort_passes<SM_FOLD>(keys_a, keys_b, vals_a, vals_b, n, nbatch, bit_lo, bit_hi, iota, (uint32_t)aux, ghist, st);
+  }
+  if (flags & QRLSH_SORT_OWNER) {
+    QR_CHECK_ARG(aux >= 1 && aux < (1ull << 32), "qrlsh_sort_u64: owner shard size %llu not in [1, 2^32)",
+                 (unsigned long long)aux);
+    // one pass: the digit is the owner rank of the id field that starts at bit_lo
+    return sort_passes<SM_OWNER>(keys_a, keys_b, vals_a, vals_b, n, nbatch, bit_lo, bit_lo + 1, iota, (uint32_t)aux, ghist,
+                                 st);
   }
   return sort_passes<SM_PLAIN>(keys_a, keys_b, vals_a, vals_b, n, nbatch, bit_lo, bit_hi, iota, 0, ghist, st);
+}
+
+// bounds_out[g] = first position whose owner (word >> lo) / shard is >= g, g = 0 .. world, for
+// words already grouped by owner (QRLSH_SORT_OWNER): the split points of the variable all-to-all.
+__global__ void owner_bounds_kernel(const uint64_t *__restrict__ w, int64_t n, int lo, uint64_t shard, int world,
+                                    int64_t *__restrict__ bounds_out) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g > world) return;
+  int64_t a = 0, b = n;
+  while (a < b) {
+    const int64_t mid = (a + b) >> 1;
+    if ((w[mid] >> lo) / shard >= (uint64_t)g) b = mid;
+    else a = mid + 1;
+  }
+  bounds_out[g] = a;
+}
+
+QRLSH_EXPORT int qrlsh_owner_bounds(const uint64_t *words, int64_t n, int32_t bit_lo, uint64_t shard, int32_t world,
+                                    int64_t *bounds_out, void *stream) {
+  QR_CHECK_ARG(n >= 0 && bit_lo >= 0 && bit_lo < 64 && shard >= 1 && world >= 1 && world <= RADIX && bounds_out,
+               "qrlsh_owner_bounds: bad arguments");
+  QR_CHECK_ARG(n == 0 || words, "qrlsh_owner_bounds: null pointer");
+  QR_LAUNCH("owner_bounds", owner_bounds_kernel, dim3((world + 1 + 63) / 64), dim3(64), 0,
+            static_cast<hipStream_t>(stream), words, n, bit_lo, shard, world, bounds_out);
+  QR_LAUNCH_CHECK("qrlsh_owner_bounds");
+  return QRLSH_OK;
 }
 
 // ==========================================================================================

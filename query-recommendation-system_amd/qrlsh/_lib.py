@@ -22,6 +22,7 @@ SIG_U16 = 1
 SORT_MIX = 1
 SORT_IOTA = 2
 SORT_FOLD = 4
+SORT_OWNER = 8
 
 _vp = ctypes.c_void_p
 _i32 = ctypes.c_int32
@@ -38,7 +39,8 @@ SIGNATURES = {
     "qrlsh_minhash": (ctypes.c_int, [_vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
     "qrlsh_band_keys": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     "qrlsh_sort_workspace_bytes": (_sz, [_i64, _i32]),
-    "qrlsh_sort_u64": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _u32, _vp, _sz, _vp]),
+    "qrlsh_sort_u64": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _u32, _u64, _vp, _sz, _vp]),
+    "qrlsh_owner_bounds": (ctypes.c_int, [_vp, _i64, _i32, _u64, _i32, _vp, _vp]),
     "qrlsh_pairs_workspace_bytes": (_sz, [_i64, _i32]),
     "qrlsh_pairs_count": (ctypes.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp, _vp]),
     "qrlsh_pairs_fill": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),

@@ -13,7 +13,7 @@ Rank g owns the contiguous query range [g*nql, (g+1)*nql) and bands {k : k // ce
   3. signature rows (compact uint16 when lossless) and norms start an ASYNC all-gather on a
      second communicator: they are only needed for scoring, so the transfer runs beside
      steps 4-5 instead of ahead of the short exchanges.
-  4. per owned band: bucket sort + pair emission over ALL queries; local sort + unique.
+  4. per owned band: bucket partition + pair emission over ALL queries; sorted by i only.
   5. pairs go to the owner of their smaller query id (variable-size all-to-all); the owner
      sorts + uniques what it received -> its share of the global candidate set.
   6. owners score their pairs against the gathered signatures; the reverse edge (j -> i) of
@@ -48,6 +48,10 @@ class HipBackend:
 
     def sort_words(self, words, lo, hi):
         return ops.sort_u64(words, None, lo, hi)[0]
+
+    def group_by_owner(self, words, lo, shard, vals=None):
+        """one stable pass that orders words (and vals) by (word >> lo) // shard"""
+        return ops.sort_u64(words, vals, lo, lo + 1, owner_shard=shard)
 
     def verify(self, sig_all, b, pairs):
         return ops.drop_unverified(sig_all, b, pairs)
@@ -132,6 +136,16 @@ def _exchange_var(chunks_sizes, send, group=None):
     return recv
 
 
+def _owner_sizes(words, lo, shard, world):
+    """per-destination counts of words already grouped by owner = (word >> lo) // shard"""
+    if words.numel() == 0:
+        return [0] * world
+    if words.is_cuda:
+        return ops.owner_sizes(words, lo, shard, world)
+    owner = torch.div(words >> lo, shard, rounding_mode="floor")      # CPU tensors (gloo tests)
+    return torch.bincount(owner, minlength=world)[:world].tolist()
+
+
 def _split_by_bounds(sorted_words, bounds):
     """sizes of the W consecutive chunks of sorted_words delimited by the W-1 `bounds` values"""
     if len(bounds) == 0:
@@ -198,15 +212,16 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
     if nb > 0:
         emitted = be.emit_pairs(owned, r)
         stats["emitted_pairs"] = int(emitted.numel())
-        mine = be.sort_unique(emitted, pair_bits) if emitted.numel() else emitted
+        # only order by i (so the list splits by owner); duplicates across this rank's few bands are
+        # rare and the owner de-duplicates anyway, so the local unique is not worth its passes
+        mine = be.group_by_owner(emitted, 32, nql)[0] if emitted.numel() else emitted
     else:
         stats["emitted_pairs"] = 0
         mine = torch.empty((0,), dtype=torch.int64, device=dev)
     del owned
 
     # 5. pairs -> owner of i
-    bounds = [(g * nql) << 32 for g in range(1, world)]
-    got = _exchange_var(_split_by_bounds(mine, bounds), mine, group)
+    got = _exchange_var(_owner_sizes(mine, 32, nql, world), mine, group)
     pairs = be.sort_unique(got, pair_bits) if got.numel() else got
 
     # 6. score on the owner; reverse edges -> owner of j
@@ -221,16 +236,17 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
         fwd_k, fwd_d = ek[0::2].contiguous(), ed[0::2].contiguous()
         rev_k, rev_d = ek[1::2].contiguous(), ed[1::2].contiguous()
         if pairs.numel():
-            rev_k, rev_d = be.sort_words_kv(rev_k, rev_d, 11, ib + 11)
-        sizes = _split_by_bounds(rev_k, [(g * nql) << 11 for g in range(1, world)])
+            rev_k, rev_d = be.group_by_owner(rev_k, 11, nql, rev_d)
+        sizes = _owner_sizes(rev_k, 11, nql, world)
         rk_in = _exchange_var(sizes, rev_k, group)
         rd_in = _exchange_var(sizes, rev_d.view(torch.int32), group)
         edges_local = (torch.cat([rk_in, fwd_k]), torch.cat([rd_in, fwd_d]))
     else:
         fwd = edges[0::2].contiguous()
-        rev = be.sort_words(edges[1::2].contiguous(), ib + 11, 2 * ib + 11) if pairs.numel() else edges[1::2].contiguous()
-        ebounds = [(g * nql) << (ib + 11) for g in range(1, world)]
-        rev_in = _exchange_var(_split_by_bounds(rev, ebounds), rev, group)
+        rev = edges[1::2].contiguous()
+        if pairs.numel():
+            rev = be.group_by_owner(rev, ib + 11, nql)[0]
+        rev_in = _exchange_var(_owner_sizes(rev, ib + 11, nql, world), rev, group)
         edges_local = torch.cat([rev_in, fwd])
 
     # 7. local top-K.  Order matters for the stable top-K sort: per src, reverse edges (dst < src,

@@ -160,7 +160,7 @@ def row_norms(sig):
 # ---------------------------------------------------------------------------
 # radix sort
 # ---------------------------------------------------------------------------
-def sort_u64(keys, vals=None, bit_lo=0, bit_hi=64, mix=False, iota=False, fold=0):
+def sort_u64(keys, vals=None, bit_lo=0, bit_hi=64, mix=False, iota=False, fold=0, owner_shard=0):
     """Stable LSD radix sort of each row of keys (int64 bit patterns, unsigned order) over
     bits [bit_lo, bit_hi) (of mix64(key) when mix).  `keys` (and vals) are consumed as one
     of the two ping-pong buffers.  Returns (sorted_keys, sorted_vals | None)."""
@@ -179,9 +179,15 @@ def sort_u64(keys, vals=None, bit_lo=0, bit_hi=64, mix=False, iota=False, fold=0
     nbytes = lib.qrlsh_sort_workspace_bytes(n, nbatch)
     ws = _ws(nbytes, keys.device)
     flags = (_lib.SORT_MIX if mix else 0) | (_lib.SORT_IOTA if iota else 0)
+    aux = 0
     if fold:
-        flags |= _lib.SORT_FOLD | (int(fold) << 8)
-    rc = _lib.check(lib.qrlsh_sort_u64(_ptr(k2), _ptr(kb), _ptr(vals), _ptr(vb), n, nbatch, bit_lo, bit_hi, flags,
+        flags |= _lib.SORT_FOLD
+        aux = int(fold)
+    if owner_shard:   # one pass: digit = (key >> bit_lo) // owner_shard  (rank owning that id)
+        flags |= _lib.SORT_OWNER
+        aux = int(owner_shard)
+        bit_hi = bit_lo + 1
+    rc = _lib.check(lib.qrlsh_sort_u64(_ptr(k2), _ptr(kb), _ptr(vals), _ptr(vb), n, nbatch, bit_lo, bit_hi, flags, aux,
                                        _ptr(ws), ws.numel(), _stream()))
     ko = kb if rc == 1 else k2
     vo = (vb if rc == 1 else vals) if vals is not None else None
@@ -198,6 +204,16 @@ def hash_bits_for(n):
     holds ~1/8 foreign keys on average (n / 2^bits <= 1/8), in whole 8-bit passes."""
     need = max(1, int(n - 1).bit_length()) + 3 if n > 1 else 8
     return min(32, max(8, (need + 7) // 8 * 8))
+
+
+def owner_sizes(words, bit_lo, shard, world):
+    """per-rank counts of words already grouped by owner = (word >> bit_lo) // shard"""
+    lib = _lib.load()
+    _need(words, torch.int64, "words", 1)
+    bounds = torch.empty((world + 1,), dtype=torch.int64, device=words.device)
+    _lib.check(lib.qrlsh_owner_bounds(_ptr(words), words.numel(), bit_lo, shard, world, _ptr(bounds), _stream()))
+    bl = bounds.tolist()
+    return [bl[g + 1] - bl[g] for g in range(world)]
 
 
 def bucket_sort(keys, hash_bits=None):

@@ -99,6 +99,11 @@ class OracleBackend:
         e[1::2] = (j << sh) | (inv << np.uint64(id_bits)) | i
         return _t(milli), _t(e.view(np.int64))
 
+    def group_by_owner(self, words, lo, shard, vals=None):
+        w = words.numpy().view(np.uint64)
+        o = np.argsort((w >> np.uint64(lo)) // np.uint64(shard), kind="stable")
+        return _t(w[o].view(np.int64)), (_t(vals.numpy()[o]) if vals is not None else None)
+
     def sort_words_kv(self, words, vals, lo, hi):
         w = words.numpy().view(np.uint64)
         d = (w >> np.uint64(lo)) & np.uint64((1 << (hi - lo)) - 1)

@@ -48,7 +48,7 @@ def test_argument_errors_do_not_need_a_gpu():
     assert b"divisible" in lib.qrlsh_last_error() or b"bad arguments" in lib.qrlsh_last_error()
     with pytest.raises(_lib.QrlshError):
         _lib.check(rc)
-    rc = lib.qrlsh_sort_u64(None, None, None, None, -1, 1, 0, 8, 0, None, 0, None)
+    rc = lib.qrlsh_sort_u64(None, None, None, None, -1, 1, 0, 8, 0, 0, None, 0, None)
     assert rc == _lib.QRLSH_EINVAL
     with pytest.raises(NotImplementedError):
         _lib.check(_lib.QRLSH_EUNSUPPORTED)
