@@ -49,6 +49,10 @@ class HipBackend:
     def sort_words(self, words, lo, hi):
         return ops.sort_u64(words, None, lo, hi)[0]
 
+    def owner_sizes(self, words, lo, shard, world):
+        """per-destination counts of words already grouped by owner = (word >> lo) // shard"""
+        return ops.owner_sizes(words, lo, shard, world) if words.numel() else [0] * world
+
     def group_by_owner(self, words, lo, shard, vals=None):
         """one stable pass that orders words (and vals) by (word >> lo) // shard"""
         return ops.sort_u64(words, vals, lo, lo + 1, owner_shard=shard)
@@ -136,26 +140,6 @@ def _exchange_var(chunks_sizes, send, group=None):
     return recv
 
 
-def _owner_sizes(words, lo, shard, world):
-    """per-destination counts of words already grouped by owner = (word >> lo) // shard"""
-    if words.numel() == 0:
-        return [0] * world
-    if words.is_cuda:
-        return ops.owner_sizes(words, lo, shard, world)
-    owner = torch.div(words >> lo, shard, rounding_mode="floor")      # CPU tensors (gloo tests)
-    return torch.bincount(owner, minlength=world)[:world].tolist()
-
-
-def _split_by_bounds(sorted_words, bounds):
-    """sizes of the W consecutive chunks of sorted_words delimited by the W-1 `bounds` values"""
-    if len(bounds) == 0:
-        return [int(sorted_words.numel())]
-    bt = torch.tensor(bounds, dtype=torch.int64, device=sorted_words.device)
-    cut = torch.searchsorted(sorted_words, bt).tolist()
-    edges = [0] + cut + [int(sorted_words.numel())]
-    return [edges[i + 1] - edges[i] for i in range(len(edges) - 1)]
-
-
 def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="all_to_all", backend=None,
                                group=None, wide_ids=None):
     """Hot path for this rank's query shard; collective over `group`.  Every rank must hold
@@ -221,7 +205,7 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
     del owned
 
     # 5. pairs -> owner of i
-    got = _exchange_var(_owner_sizes(mine, 32, nql, world), mine, group)
+    got = _exchange_var(be.owner_sizes(mine, 32, nql, world), mine, group)
     pairs = be.sort_unique(got, pair_bits) if got.numel() else got
 
     # 6. score on the owner; reverse edges -> owner of j
@@ -237,7 +221,7 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
         rev_k, rev_d = ek[1::2].contiguous(), ed[1::2].contiguous()
         if pairs.numel():
             rev_k, rev_d = be.group_by_owner(rev_k, 11, nql, rev_d)
-        sizes = _owner_sizes(rev_k, 11, nql, world)
+        sizes = be.owner_sizes(rev_k, 11, nql, world)
         rk_in = _exchange_var(sizes, rev_k, group)
         rd_in = _exchange_var(sizes, rev_d.view(torch.int32), group)
         edges_local = (torch.cat([rk_in, fwd_k]), torch.cat([rd_in, fwd_d]))
@@ -246,7 +230,7 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
         rev = edges[1::2].contiguous()
         if pairs.numel():
             rev = be.group_by_owner(rev, ib + 11, nql)[0]
-        rev_in = _exchange_var(_owner_sizes(rev, ib + 11, nql, world), rev, group)
+        rev_in = _exchange_var(be.owner_sizes(rev, ib + 11, nql, world), rev, group)
         edges_local = torch.cat([rev_in, fwd])
 
     # 7. local top-K.  Order matters for the stable top-K sort: per src, reverse edges (dst < src,

@@ -99,6 +99,10 @@ class OracleBackend:
         e[1::2] = (j << sh) | (inv << np.uint64(id_bits)) | i
         return _t(milli), _t(e.view(np.int64))
 
+    def owner_sizes(self, words, lo, shard, world):
+        w = words.numpy().view(np.uint64)
+        return np.bincount(((w >> np.uint64(lo)) // np.uint64(shard)).astype(np.int64), minlength=world)[:world].tolist()
+
     def group_by_owner(self, words, lo, shard, vals=None):
         w = words.numpy().view(np.uint64)
         o = np.argsort((w >> np.uint64(lo)) // np.uint64(shard), kind="stable")
