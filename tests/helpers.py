@@ -5,7 +5,7 @@ import numpy as np
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
-FULL = ["cfg1_hotpath", "full_p180", "full_p160", "full_p320", "full_p200", "full_p160_wrap", "full_p160_ties",
+FULL = ["cfg1_hotpath", "cfg1b_hotpath", "full_p180", "full_p160", "full_p320", "full_p200", "full_p160_wrap", "full_p160_ties",
         "full_p100_r5", "full_p50_r5_wrap"]   # the last two: wide bands (r = 5), the reference's pick for PERM = 100 / 50
 PIECES = ["pieces_p128_b32", "pieces_p256_b64", "pieces_p128_b32_wrap", "pieces_p96_b12"]   # last: r = 8
 
@@ -85,3 +85,25 @@ def recall_at_k(ref_src, ref_dst, ref_val, src, dst, val, k=10):
             if d in ids or v == cutoff:
                 hit += 1
     return hit / max(tot, 1)
+
+
+GENERATOR_SETS = ["cfg1", "cfg1b"]   # two data sets written by the reference's resources/generator.py (different seeds)
+
+
+def generator_table_and_queries(sub):
+    """the table columns (as the reference compares them: strings) and the (nq, nfeat) query matrix
+    of a generator-default data set under tests/golden/<sub>/"""
+    import pandas as pd
+    gdir = os.path.join(GOLDEN, sub)
+    dataset = pd.read_csv(os.path.join(gdir, "dataset.csv"), dtype=str)
+    feats = list(dataset.columns)[1:]
+    qrows = []
+    with open(os.path.join(gdir, "queries.csv")) as fh:
+        for line in fh:
+            vals = line.rstrip("\n").split(",")
+            el = ["" for _ in feats]
+            for v in vals[1:]:
+                a = v.split("=")
+                el[feats.index(a[0])] = a[1]
+            qrows.append(el)
+    return [dataset[f].to_numpy() for f in feats], np.array(qrows, dtype=object)

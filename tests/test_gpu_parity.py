@@ -8,7 +8,8 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import FULL, PIECES, GOLDEN, load, pairs_u64, check_topk_tie_aware
+from helpers import (FULL, PIECES, GOLDEN, GENERATOR_SETS, load, pairs_u64, check_topk_tie_aware,
+                     generator_table_and_queries)
 
 pytestmark = pytest.mark.gpu
 
@@ -242,13 +243,14 @@ def test_full_path_matches_reference_tie_aware(name):
     assert np.array_equal(res.val.cpu().numpy(), r["val"])
 
 
-def test_recommender_dropin_on_generator_default_inputs():
+@pytest.mark.parametrize("sub", GENERATOR_SETS)
+def test_recommender_dropin_on_generator_default_inputs(sub):
     """config 1: the CSVs produced by the reference's resources/generator.py, through the
     drop-in Recommender, under the same np.random.seed as the golden capture."""
     import pandas as pd
     import recommender as R
-    g = load("cfg1_hotpath")
-    gdir = os.path.join(GOLDEN, "cfg1")
+    g = load(sub + "_hotpath")
+    gdir = os.path.join(GOLDEN, sub)
     dataset = pd.read_csv(os.path.join(gdir, "dataset.csv"), dtype=str)
     feats = list(dataset.columns)[1:]
     qrows, qids = [], []
@@ -418,12 +420,12 @@ def test_overflowing_part_falls_back_to_general_path():
 # ---------------------------------------------------------------------------- N2: answer sets
 def test_device_answer_sets_match_reference_and_oracle():
     from qrlsh import answers
-    from test_oracle_golden import _cfg1_table_and_queries
-    g = load("cfg1_hotpath")
-    cols, queries = _cfg1_table_and_queries()
-    idx = answers.build_answer_index(cols, DEV)
-    off, rows = answers.answer_sets(idx, answers.encode_queries(idx, queries))
-    assert np.array_equal(off.cpu().numpy(), g["offsets"]) and np.array_equal(rows.cpu().numpy(), g["rows"])
+    for sub in GENERATOR_SETS:
+        g = load(sub + "_hotpath")
+        cols, queries = generator_table_and_queries(sub)
+        idx = answers.build_answer_index(cols, DEV)
+        off, rows = answers.answer_sets(idx, answers.encode_queries(idx, queries))
+        assert np.array_equal(off.cpu().numpy(), g["offsets"]) and np.array_equal(rows.cpu().numpy(), g["rows"])
     # random tables: D not a multiple of 32, > 64 words per row, absent values, unconstrained queries
     rng = np.random.default_rng(9)
     for (D, nfeat, card, nq) in [(1, 1, 1, 3), (33, 2, 3, 40), (1000, 5, 7, 300), (70001, 3, 50, 500), (5000, 6, 2, 200)]:
@@ -505,14 +507,15 @@ def test_wide_id_edge_format_gives_the_same_topk():
 
 
 # ---------------------------------------------------------------------------- N1 / N3 / N4
-def test_compute_scores_dropin_matches_reference_on_generator_default_inputs():
+@pytest.mark.parametrize("sub", GENERATOR_SETS)
+def test_compute_scores_dropin_matches_reference_on_generator_default_inputs(sub):
     """main.py's flow on the generator-default CSVs through the drop-in Recommender: pandas
     ingest (N3), device answer sets (N2), hot path, sklearn user similarity (N4), device
     prediction loop (N1) -> the reference's finalPredictions, cell for cell."""
     import pandas as pd
     import recommender as R
-    g = load("cfg1_scores")
-    gdir = os.path.join(GOLDEN, "cfg1")
+    g = load(sub + "_scores")
+    gdir = os.path.join(GOLDEN, sub)
     rec = R.Recommender()
     rec.verbose = False
     dataset = pd.read_csv(os.path.join(gdir, "dataset.csv"))

@@ -4,7 +4,8 @@ import numpy as np
 import pytest
 
 from oracle import oracle as O
-from helpers import FULL, PIECES, load, pairs_u64, check_topk_tie_aware
+from helpers import (FULL, PIECES, GENERATOR_SETS, load, pairs_u64, check_topk_tie_aware,
+                     generator_table_and_queries)
 
 
 @pytest.mark.parametrize("name", FULL + PIECES)
@@ -16,7 +17,7 @@ def test_minhash_matches_reference(name):
     assert np.array_equal(sig, g["sig"])
 
 
-@pytest.mark.parametrize("name", ["cfg1_hotpath", "full_p160_ties"])
+@pytest.mark.parametrize("name", ["cfg1_hotpath", "cfg1b_hotpath", "full_p160_ties"])
 def test_naive_minhash_matches_reference(name):
     g = load(name)
     perm = O.legacy_permutations(int(g["seed"]), int(g["P"]), int(g["D"]))
@@ -111,38 +112,21 @@ def test_synth_generator_is_a_pure_function_of_index():
         assert np.all(np.diff(s) > 0) and s.min() >= 0 and s.max() < 32768
 
 
-def _cfg1_table_and_queries():
-    import os
-    import pandas as pd
-    from helpers import GOLDEN
-    gdir = os.path.join(GOLDEN, "cfg1")
-    dataset = pd.read_csv(os.path.join(gdir, "dataset.csv"), dtype=str)
-    feats = list(dataset.columns)[1:]
-    qrows = []
-    with open(os.path.join(gdir, "queries.csv")) as fh:
-        for line in fh:
-            vals = line.rstrip("\n").split(",")
-            el = ["" for _ in feats]
-            for v in vals[1:]:
-                a = v.split("=")
-                el[feats.index(a[0])] = a[1]
-            qrows.append(el)
-    return [dataset[f].to_numpy() for f in feats], np.array(qrows, dtype=object)
-
-
-def test_answer_sets_match_reference_compute_shingles():
+@pytest.mark.parametrize("sub", GENERATOR_SETS)
+def test_answer_sets_match_reference_compute_shingles(sub):
     """N2: the restated compute_shingles against the CSR derived from the reference's own
     compute_shingles() output on the generator-default CSVs (tools/make_golden.py)."""
-    g = load("cfg1_hotpath")
-    cols, queries = _cfg1_table_and_queries()
+    g = load(sub + "_hotpath")
+    cols, queries = generator_table_and_queries(sub)
     off, rows = O.answer_sets(cols, queries)
     assert np.array_equal(off, g["offsets"]) and np.array_equal(rows, g["rows"])
 
 
-def test_user_similarity_and_prediction_loop_match_reference():
+@pytest.mark.parametrize("sub", GENERATOR_SETS)
+def test_user_similarity_and_prediction_loop_match_reference(sub):
     """N4 + N1: restated compute_userSimilarities / compute_scores against the reference's own
-    outputs on the generator-default CSVs (tests/golden/cfg1_scores.npz)."""
-    g, h = load("cfg1_scores"), load("cfg1_hotpath")
+    outputs on the generator-default CSVs (tests/golden/<sub>_scores.npz)."""
+    g, h = load(sub + "_scores"), load(sub + "_hotpath")
     us = O.user_similarities(g["ratings"])
     for u in range(len(g["ratings"])):
         n = int((g["us_idx"][u] >= 0).sum())

@@ -19,7 +19,7 @@ How the reference is run:
 
 Usage:  python tools/make_golden.py            (rewrites the round-1 base fixtures)
         python tools/make_golden.py NAME...    (only the named later additions: full_p100_r5,
-                                                full_p50_r5_wrap, pieces_p96_b12, cfg1_scores)
+                                                full_p50_r5_wrap, pieces_p96_b12, cfg1_scores, cfg1b)
 """
 import os
 import sys
@@ -237,7 +237,7 @@ def synth_csr(nq, D, seed, cluster=8, mean=16, p_replace=0.15, n_empty=0, n_dup=
 
 
 # --------------------------------------------------------------------------
-def fixture_generator_default(recommender_mod, lsh_mod):
+def fixture_generator_default(recommender_mod, lsh_mod, sub="cfg1", gen_seed=20250114, name="cfg1_hotpath"):
     """config 1: resources/generator.py defaults -> 4 CSVs -> reference hot path."""
     scratch = tempfile.mkdtemp(prefix="qr_gen_")
     try:
@@ -247,8 +247,11 @@ def fixture_generator_default(recommender_mod, lsh_mod):
         sys.path.insert(0, os.path.join(REF, "resources"))
         import generator  # noqa
         sys.path.pop(0)
-        random.seed(20250114)
-        np.random.seed(20250114)
+        for attr, empty in (("user_tastes", {}), ("queries", []), ("user_queries", {}), ("usersIDs", []),
+                            ("queriesIDs", [])):
+            setattr(generator, attr, type(empty)())          # module-level state: start clean on a second run
+        random.seed(gen_seed)
+        np.random.seed(gen_seed)
         with _quiet():
             generator.get_data()
             generator.create_dataset()
@@ -256,10 +259,10 @@ def fixture_generator_default(recommender_mod, lsh_mod):
             generator.create_queries()
             generator.create_matrix()
         os.chdir(cwd)
-        gdir = os.path.join(OUT, "cfg1")
+        gdir = os.path.join(OUT, sub)
         os.makedirs(gdir, exist_ok=True)
-        for name in ("dataset", "users", "queries", "utility_matrix"):
-            shutil.copy(os.path.join(scratch, "output", name + ".csv"), os.path.join(gdir, name + ".csv"))
+        for fname in ("dataset", "users", "queries", "utility_matrix"):
+            shutil.copy(os.path.join(scratch, "output", fname + ".csv"), os.path.join(gdir, fname + ".csv"))
     finally:
         shutil.rmtree(scratch, ignore_errors=True)
 
@@ -305,17 +308,17 @@ def fixture_generator_default(recommender_mod, lsh_mod):
     pairs = _pairs_array(cands)
     qids_a, off, idx, val = _sim_dict_to_arrays(qs)
     np.savez_compressed(
-        os.path.join(OUT, "cfg1_hotpath.npz"),
+        os.path.join(OUT, name + ".npz"),
         D=D, P=P, b=b, K=K, seed=seed, offsets=offsets, rows=rows,
         sig=sig.astype(np.int32), pairs=pairs, pair_cos=_all_pair_cos(sig, pairs),
         qs_q=qids_a, qs_off=off, qs_idx=idx, qs_val=val)
-    print("cfg1: D=%d nq=%d P=%d b=%d K=%d pairs=%d sims=%d" % (D, nq, P, b, K, len(pairs), len(qids_a)))
+    print("%s: D=%d nq=%d P=%d b=%d K=%d pairs=%d sims=%d" % (name, D, nq, P, b, K, len(pairs), len(qids_a)))
 
 
-def fixture_cfg1_scores(recommender_mod, lsh_mod):
+def fixture_cfg1_scores(recommender_mod, lsh_mod, sub="cfg1", name="cfg1_scores"):
     """config 1 through the reference's whole compute_scores (query + user similarity + hybrid
     prediction loop, recommender.py:216-343) on the committed generator-default CSVs."""
-    gdir = os.path.join(OUT, "cfg1")
+    gdir = os.path.join(OUT, sub)
     dataset = pd.read_csv(os.path.join(gdir, "dataset.csv"), dtype=str)
     feats = list(dataset.columns)[1:]
     qrows, qids = [], []
@@ -358,10 +361,10 @@ def fixture_cfg1_scores(recommender_mod, lsh_mod):
         n = len(us[u]["indexes"])
         us_idx[u, :n] = us[u]["indexes"]
         us_val[u, :n] = us[u]["values"]
-    np.savez_compressed(os.path.join(OUT, "cfg1_scores.npz"), seed=seed, P=180, ratings=ratings,
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), seed=seed, P=180, ratings=ratings,
                         us_idx=us_idx, us_val=us_val, final=final.to_numpy().astype(np.int64),
                         to_predict=np.asarray(to_predict, dtype=np.int64), missed=np.asarray(missed, dtype=np.int64))
-    print("cfg1_scores: users=%d queries=%d to_predict=%d missed=%d" % (nu, len(qids), len(to_predict), len(missed)))
+    print("%s: users=%d queries=%d to_predict=%d missed=%d" % (name, nu, len(qids), len(to_predict), len(missed)))
 
 
 def fixture_full(recommender_mod, lsh_mod, name, nq, D, P, seed, data_seed, **kw):
@@ -454,6 +457,9 @@ def main():
                          n_empty=2, n_dup=3, cluster=6, mean=8)
         if want("cfg1_scores"):
             fixture_cfg1_scores(recommender_mod, lsh_mod)
+        if want("cfg1b"):     # a second generator-default data set (different generator seed)
+            fixture_generator_default(recommender_mod, lsh_mod, sub="cfg1b", gen_seed=7, name="cfg1b_hotpath")
+            fixture_cfg1_scores(recommender_mod, lsh_mod, sub="cfg1b", name="cfg1b_scores")
         if want("pieces_p96_b12"):
             fixture_pieces(recommender_mod, lsh_mod, "pieces_p96_b12", nq=500, D=3000, P=96, b=12, seed=29,
                            data_seed=10, n_empty=3, n_dup=3, p_replace=0.05)
