@@ -19,7 +19,7 @@ class AnswerIndex:
         self.bitmaps = bitmaps        # int32 tensor [nrows_total + 1, wpr] (last row all zero)
         self.D = D
         self.wpr = wpr
-        self.value_rows = value_rows  # list (per feature) of dict value -> bitmap row
+        self.value_rows = value_rows  # per feature: (sorted distinct values, first bitmap row)
         self.zero_row = zero_row
         self.nfeat = len(value_rows)
 
@@ -34,7 +34,7 @@ def build_answer_index(columns, device="cuda"):
     for col in columns:
         col = np.asarray(col)
         vals, inv = np.unique(col, return_inverse=True)
-        value_rows.append({v: nrows + k for k, v in enumerate(vals.tolist())})
+        value_rows.append((vals, nrows))                 # sorted distinct values, first bitmap row
         onehot = np.zeros((len(vals), wpr * 32), dtype=np.uint8)
         onehot[inv, np.arange(D)] = 1
         maps.append(np.packbits(onehot, axis=1, bitorder="little").view(np.uint32))
@@ -52,12 +52,16 @@ def encode_queries(index, queries):
     nq = queries.shape[0]
     out = np.full((nq, index.nfeat), -1, dtype=np.int32)
     for f in range(index.nfeat):
-        colmap = index.value_rows[f]
-        col = queries[:, f]
-        for q in range(nq):
-            v = col[q]
-            if v != "":
-                out[q, f] = colmap.get(v, index.zero_row)
+        vals, base = index.value_rows[f]
+        col = queries[:, f].astype(vals.dtype if vals.dtype.kind in "US" else object)
+        want = col != ""
+        if not want.any():
+            continue
+        c = col[want]
+        pos = np.searchsorted(vals, c)
+        pos_c = np.minimum(pos, len(vals) - 1)
+        found = vals[pos_c] == c
+        out[want, f] = np.where(found, base + pos_c, index.zero_row).astype(np.int32)
     return out
 
 

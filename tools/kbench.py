@@ -51,7 +51,7 @@ def main():
         f1 = rng.integers(0, nfeat, size=a.nq)
         f2 = (f1 + 1 + rng.integers(0, nfeat - 1, size=a.nq)) % nfeat
         for f in range(nfeat):
-            base = idx.value_rows[f]["0"]
+            base = idx.value_rows[f][1]     # codes are str(0..card-1); bitmap rows follow the sorted order of the strings
             qr[f1 == f, f] = base + rng.integers(0, card, size=int((f1 == f).sum()))
             qr[f2 == f, f] = base + rng.integers(0, card, size=int((f2 == f).sum()))
         qrows = torch.from_numpy(qr).to(dev)
@@ -61,7 +61,7 @@ def main():
         off, rows_ = run()
         print("answer sets: nq=%d D=%d nnz=%d mean=%.2f" % (a.nq, a.drows, rows_.numel(), rows_.numel() / a.nq))
         from oracle import oracle as O
-        inv = [{v: k for k, v in m.items()} for m in idx.value_rows]
+        inv = [{base + k: v for k, v in enumerate(vals.tolist())} for (vals, base) in idx.value_rows]
         ns = 2000
         qs = np.full((ns, nfeat), "", dtype=object)
         for i in range(ns):
