@@ -280,8 +280,18 @@ def cpu_leg(nq_s, D, P, b, dev, threads):
                  and np.array_equal(res.milli.cpu().numpy(), milli))
     recall = recall_at_k(s, d, v, res.src.cpu().numpy(), res.dst.cpu().numpy(), res.val.cpu().numpy(), 10)
     total = t3 - t0
+    # the same port on ONE thread (the reference itself is single-threaded), on a smaller sample
+    n1 = min(nq_s, 200_000)
+    o1, r1 = O.synth_csr(n1, D, seed=0)
+    O.set_threads(1)
+    t4 = time.perf_counter()
+    O.query_similarities(o1, r1, D, P, b, pipeline.max_candidates(n1), 42)
+    t5 = time.perf_counter()
+    O.set_threads(cores)
     base = {
         "value": round(nq_s / total, 1), "unit": "signatures/s", "cores": cores, "kind": "port",
+        "single_thread": {"value": round(n1 / (t5 - t4), 1), "unit": "signatures/s", "cores": 1,
+                          "sample": "whole hot path on nq=%d, 1 thread" % n1, "seconds": round(t5 - t4, 3)},
         "sample": "whole hot path on nq=%d queries of the same synthetic recipe (P=%d, b=%d, D=%d), oracle/qr_oracle.c with OpenMP, %d threads"
                   % (nq_s, P, b, D, cores),
         "seconds": round(total, 3),

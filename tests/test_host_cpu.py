@@ -113,3 +113,13 @@ def test_no_product_module_imports_the_oracle():
                 checked += 1
                 assert not pat.search(open(os.path.join(dirpath, f)).read()), f
     assert checked >= 10
+
+
+def test_generator_write_csv_shim(tmp_path, monkeypatch):
+    """main.py:2,109 uses `from resources import generator; generator.write_csv(...)`"""
+    from resources import generator
+    monkeypatch.chdir(tmp_path)
+    generator.write_csv("final_predictions", ["Q1", "Q2"], [["U1", 3, 4], ["U2", 0, 7]])
+    generator.write_csv("noheader", None, [[1, 2]])
+    assert open(tmp_path / "output" / "final_predictions.csv").read().splitlines() == ["Q1,Q2", "U1,3,4", "U2,0,7"]
+    assert open(tmp_path / "output" / "noheader.csv").read().splitlines() == ["1,2"]
