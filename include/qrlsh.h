@@ -195,6 +195,16 @@ int qrlsh_answer_sets_fill(const uint32_t *bitmaps, int64_t words_per_row, int64
                            const int32_t *qrows, int64_t nq, int32_t nfeat, const int64_t *offsets,
                            int32_t *rows_out, void *stream);
 
+/* one-sweep form of the two calls above: sweep = sizes + the first 64 row ids of every query
+ * parked in slots_out[nq][64]; after the exclusive scan of the sizes, compact moves the slots of the
+ * queries with <= 64 rows to their CSR positions.  Queries with more rows (sizes_out > 64) still
+ * need qrlsh_answer_sets_fill (pass it a qrows/offsets subset, or call it for all). */
+int qrlsh_answer_sets_sweep(const uint32_t *bitmaps, int64_t words_per_row, int64_t D,
+                            const int32_t *qrows, int64_t nq, int32_t nfeat, int32_t *sizes_out,
+                            int32_t *slots_out, void *stream);
+int qrlsh_answer_sets_compact(const int32_t *slots, const int64_t *offsets, int64_t nq,
+                              int32_t *rows_out, void *stream);
+
 /* ---- N1: hybrid prediction loop (the consumer of the hot path's output) ---------------------
  * Replaces the per-cell loop of Recommender.compute_scores, recommender.py:301-331, and
  * weighted_average, recommender.py:36-47.  ratings int32 [nu][nq] (0 = missing).  Query

@@ -14,7 +14,13 @@
 // qrows[q][f] : bitmap row of query q's value for feature f, or -1 when the feature is
 //               unconstrained ("" in the reference, :86); a value absent from the table must
 //               point at an all-zero bitmap row.
-template <bool FILL>
+// MODE 0: sizes only.  MODE 1: write the rows at offsets[q] (needs the scanned sizes).
+// MODE 2: ONE sweep that records the size AND parks the first AS_SLOT row ids of every query in a
+//         padded slot (tmp[q][AS_SLOT]); answer_sets_compact_kernel then moves the slots to their
+//         CSR positions, and only queries with more than AS_SLOT rows (rare) are swept again.
+constexpr int AS_SLOT = 64;
+
+template <int MODE>
 __global__ __launch_bounds__(256) void answer_sets_kernel(const uint32_t *__restrict__ bitmaps, int64_t wpr,
                                                           int64_t D, const int32_t *__restrict__ qrows, int64_t nq,
                                                           int nfeat,
@@ -26,6 +32,7 @@ __global__ __launch_bounds__(256) void answer_sets_kernel(const uint32_t *__rest
   if (q >= nq) return;  // wave-uniform
   // the (at most 64) bitmap rows of this query, one per lane
   const int32_t myrow = lane < nfeat ? qrows[q * nfeat + lane] : -1;
+  constexpr bool FILL = MODE == 1;
   int64_t out = FILL ? offsets[q] : 0;
   uint32_t total = 0;
   for (int64_t w0 = 0; w0 < wpr; w0 += WAVE) {
@@ -37,8 +44,22 @@ __global__ __launch_bounds__(256) void answer_sets_kernel(const uint32_t *__rest
       if (r >= 0 && w < wpr) word &= bitmaps[(size_t)r * wpr + w];
     }
     const uint32_t pc = (uint32_t)__popc(word);
-    if (!FILL) {
+    if (MODE == 0) {
       total += pc;
+    } else if (MODE == 2) {
+      uint32_t inc = pc;
+#pragma unroll
+      for (int d = 1; d < WAVE; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d, WAVE);
+        if (lane >= d) inc += o;
+      }
+      uint32_t p = total + (inc - pc);  // total is wave-uniform here
+      while (word && p < (uint32_t)AS_SLOT) {
+        const int bit = __ffs(word) - 1;
+        rows[q * AS_SLOT + p++] = (int32_t)(w * 32 + bit);
+        word &= word - 1;
+      }
+      total += __shfl(inc, WAVE - 1, WAVE);
     } else {
       // exclusive prefix of the lanes' popcounts: where this lane's rows start
       uint32_t inc = pc;
@@ -56,11 +77,26 @@ __global__ __launch_bounds__(256) void answer_sets_kernel(const uint32_t *__rest
       out += __shfl(inc, WAVE - 1, WAVE);
     }
   }
-  if (!FILL) {
+  if (MODE == 0) {
 #pragma unroll
     for (int m = 1; m < WAVE; m <<= 1) total += __shfl_xor(total, m, WAVE);
     if (lane == 0) sizes[q] = (int32_t)total;
+  } else if (MODE == 2) {
+    if (lane == 0) sizes[q] = (int32_t)total;
   }
+}
+
+// slots -> CSR: one wave per query copies its (at most AS_SLOT) parked row ids; larger answer sets
+// are flagged (big[q] = 1 via sizes) for the caller's second sweep.
+__global__ __launch_bounds__(256) void answer_sets_compact_kernel(const int32_t *__restrict__ tmp,
+                                                                  const int64_t *__restrict__ offsets, int64_t nq,
+                                                                  int32_t *__restrict__ rows) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (q >= nq) return;
+  const int64_t lo = offsets[q];
+  const int64_t n = offsets[q + 1] - lo;
+  if (n <= AS_SLOT && lane < n) rows[lo + lane] = tmp[q * AS_SLOT + lane];
 }
 
 static int answers_check(const uint32_t *bitmaps, int64_t wpr, int64_t D, const int32_t *qrows, int64_t nq,
@@ -79,7 +115,7 @@ QRLSH_EXPORT int qrlsh_answer_sets_count(const uint32_t *bitmaps, int64_t words_
   if (rc != QRLSH_OK) return rc;
   if (nq == 0) return QRLSH_OK;
   QR_CHECK_ARG(sizes_out, "qrlsh_answer_sets_count: null output");
-  QR_LAUNCH("answers_count", (answer_sets_kernel<false>), dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 0,
+  QR_LAUNCH("answers_count", (answer_sets_kernel<0>), dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 0,
             static_cast<hipStream_t>(stream), bitmaps, words_per_row, D, qrows, nq, nfeat, sizes_out,
             (const int64_t *)nullptr, (int32_t *)nullptr);
   QR_LAUNCH_CHECK("qrlsh_answer_sets_count");
@@ -93,9 +129,36 @@ QRLSH_EXPORT int qrlsh_answer_sets_fill(const uint32_t *bitmaps, int64_t words_p
   if (rc != QRLSH_OK) return rc;
   if (nq == 0) return QRLSH_OK;
   QR_CHECK_ARG(offsets, "qrlsh_answer_sets_fill: null offsets");
-  QR_LAUNCH("answers_fill", (answer_sets_kernel<true>), dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 0,
+  QR_LAUNCH("answers_fill", (answer_sets_kernel<1>), dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 0,
             static_cast<hipStream_t>(stream), bitmaps, words_per_row, D, qrows, nq, nfeat, (int32_t *)nullptr, offsets,
             rows_out);
   QR_LAUNCH_CHECK("qrlsh_answer_sets_fill");
+  return QRLSH_OK;
+}
+
+// One-sweep form: sizes_out[q] = |A(q)| and the first 64 row ids of every query parked in
+// slots_out[nq][64]; follow with an exclusive scan of the sizes and qrlsh_answer_sets_compact.
+QRLSH_EXPORT int qrlsh_answer_sets_sweep(const uint32_t *bitmaps, int64_t words_per_row, int64_t D,
+                                         const int32_t *qrows, int64_t nq, int32_t nfeat, int32_t *sizes_out,
+                                         int32_t *slots_out, void *stream) {
+  const int rc = answers_check(bitmaps, words_per_row, D, qrows, nq, nfeat, "qrlsh_answer_sets_sweep");
+  if (rc != QRLSH_OK) return rc;
+  if (nq == 0) return QRLSH_OK;
+  QR_CHECK_ARG(sizes_out && slots_out, "qrlsh_answer_sets_sweep: null output");
+  QR_LAUNCH("answers_sweep", (answer_sets_kernel<2>), dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 0,
+            static_cast<hipStream_t>(stream), bitmaps, words_per_row, D, qrows, nq, nfeat, sizes_out,
+            (const int64_t *)nullptr, slots_out);
+  QR_LAUNCH_CHECK("qrlsh_answer_sets_sweep");
+  return QRLSH_OK;
+}
+
+QRLSH_EXPORT int qrlsh_answer_sets_compact(const int32_t *slots, const int64_t *offsets, int64_t nq,
+                                           int32_t *rows_out, void *stream) {
+  QR_CHECK_ARG(nq >= 0, "qrlsh_answer_sets_compact: bad nq");
+  if (nq == 0) return QRLSH_OK;
+  QR_CHECK_ARG(slots && offsets && rows_out, "qrlsh_answer_sets_compact: null pointer");
+  QR_LAUNCH("answers_compact", answer_sets_compact_kernel, dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 0,
+            static_cast<hipStream_t>(stream), slots, offsets, nq, rows_out);
+  QR_LAUNCH_CHECK("qrlsh_answer_sets_compact");
   return QRLSH_OK;
 }

@@ -57,6 +57,8 @@ SIGNATURES = {
     "qrlsh_topk_fill": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "qrlsh_answer_sets_count": (ctypes.c_int, [_vp, _i64, _i64, _vp, _i64, _i32, _vp, _vp]),
     "qrlsh_answer_sets_fill": (ctypes.c_int, [_vp, _i64, _i64, _vp, _i64, _i32, _vp, _vp, _vp]),
+    "qrlsh_answer_sets_sweep": (ctypes.c_int, [_vp, _i64, _i64, _vp, _i64, _i32, _vp, _vp, _vp]),
+    "qrlsh_answer_sets_compact": (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "qrlsh_predict": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i32, ctypes.c_double, ctypes.c_double,
                                      ctypes.c_double, _vp, _vp]),
     "qrlsh_prof_enable": (ctypes.c_int, [ctypes.c_int]),

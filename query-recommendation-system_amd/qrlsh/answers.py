@@ -65,8 +65,14 @@ def encode_queries(index, queries):
     return out
 
 
-def answer_sets(index, qrows):
-    """-> (offsets int64 [nq+1], rows int32 [nnz]) on the device; rows ascending per query."""
+SLOT = 64   # row ids parked per query by the one-sweep form (AS_SLOT in csrc/answers.hip)
+
+
+def answer_sets(index, qrows, one_sweep=True):
+    """-> (offsets int64 [nq+1], rows int32 [nnz]) on the device; rows ascending per query.
+
+    one_sweep: AND the bitmaps once, parking up to 64 row ids per query, then compact; only when
+    some answer set is larger does the exact fill pass run as well (it rewrites every query)."""
     lib = _lib.load()
     dev = index.bitmaps.device
     if not isinstance(qrows, torch.Tensor):
@@ -74,12 +80,24 @@ def answer_sets(index, qrows):
     _need(qrows, torch.int32, "qrows", 2)
     nq, nfeat = qrows.shape
     sizes = torch.empty((nq,), dtype=torch.int32, device=dev)
-    _lib.check(lib.qrlsh_answer_sets_count(_ptr(index.bitmaps), index.wpr, index.D, _ptr(qrows), nq, nfeat,
-                                           _ptr(sizes), _stream()))
     offsets = torch.zeros((nq + 1,), dtype=torch.int64, device=dev)
+    slots = None
+    if one_sweep and nq:
+        slots = torch.empty((nq, SLOT), dtype=torch.int32, device=dev)
+        _lib.check(lib.qrlsh_answer_sets_sweep(_ptr(index.bitmaps), index.wpr, index.D, _ptr(qrows), nq, nfeat,
+                                               _ptr(sizes), _ptr(slots), _stream()))
+    else:
+        _lib.check(lib.qrlsh_answer_sets_count(_ptr(index.bitmaps), index.wpr, index.D, _ptr(qrows), nq, nfeat,
+                                               _ptr(sizes), _stream()))
     torch.cumsum(sizes, dim=0, out=offsets[1:])
-    nnz = int(offsets[-1].item()) if nq else 0
+    if nq:
+        nnz, biggest = torch.stack([offsets[-1], sizes.max().to(torch.int64)]).tolist()
+    else:
+        nnz, biggest = 0, 0
     rows = torch.empty((nnz,), dtype=torch.int32, device=dev)
-    _lib.check(lib.qrlsh_answer_sets_fill(_ptr(index.bitmaps), index.wpr, index.D, _ptr(qrows), nq, nfeat,
-                                          _ptr(offsets), _ptr(rows), _stream()))
+    if slots is not None and biggest <= SLOT:
+        _lib.check(lib.qrlsh_answer_sets_compact(_ptr(slots), _ptr(offsets), nq, _ptr(rows), _stream()))
+    elif nq:
+        _lib.check(lib.qrlsh_answer_sets_fill(_ptr(index.bitmaps), index.wpr, index.D, _ptr(qrows), nq, nfeat,
+                                              _ptr(offsets), _ptr(rows), _stream()))
     return offsets, rows

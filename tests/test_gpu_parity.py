@@ -559,3 +559,24 @@ def test_prediction_kernel_equals_oracle_on_random_inputs():
         out = predict.fill_predictions(ratings, torch.tensor(src, dtype=torch.int32), torch.tensor(dst, dtype=torch.int32),
                                        torch.tensor(mil, dtype=torch.int32), us, device=DEV)
         assert np.array_equal(out.cpu().numpy(), ref)
+
+
+def test_answer_sets_one_sweep_equals_count_then_fill():
+    from qrlsh import answers
+    rng = np.random.default_rng(31)
+    for (D, card, two) in [(20000, 30, True), (3000, 4, False), (64 * 32, 32, False)]:
+        cols = [rng.integers(0, card, size=D).astype(str) for _ in range(3)]
+        nq = 4000
+        q = np.full((nq, 3), "", dtype=object)
+        q[:, 0] = rng.integers(0, card, size=nq).astype(str)
+        if two:
+            q[:, 2] = rng.integers(0, card, size=nq).astype(str)
+        idx = answers.build_answer_index(cols, DEV)
+        qr = answers.encode_queries(idx, q)
+        a_off, a_rows = answers.answer_sets(idx, qr, one_sweep=True)
+        b_off, b_rows = answers.answer_sets(idx, qr, one_sweep=False)
+        assert torch.equal(a_off, b_off) and torch.equal(a_rows, b_rows)
+        sizes = np.diff(a_off.cpu().numpy())
+        assert (sizes.max() <= 64) == two or not two     # first case exercises the compact path, the others the refill
+        roff, rrows = O.answer_sets(cols, q[:300])
+        assert np.array_equal(a_off.cpu().numpy()[:301], roff) and np.array_equal(a_rows.cpu().numpy()[:roff[-1]], rrows)
