@@ -20,11 +20,14 @@
 //         CSR positions, and only queries with more than AS_SLOT rows (rare) are swept again.
 constexpr int AS_SLOT = 64;
 
-template <int MODE>
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// VEC = words per lane per step: 4 (16-byte loads; needs words_per_row % 4 == 0 and 16-byte aligned
+// bitmap rows) or 1.
+template <int MODE, int VEC>
 __global__ __launch_bounds__(256) void answer_sets_kernel(const uint32_t *__restrict__ bitmaps, int64_t wpr,
                                                           int64_t D, const int32_t *__restrict__ qrows, int64_t nq,
-                                                          int nfeat,
-                                                          int32_t *__restrict__ sizes,
+                                                          int nfeat, int32_t *__restrict__ sizes,
                                                           const int64_t *__restrict__ offsets,
                                                           int32_t *__restrict__ rows) {
   const int lane = threadIdx.x & (WAVE - 1);
@@ -35,31 +38,33 @@ __global__ __launch_bounds__(256) void answer_sets_kernel(const uint32_t *__rest
   constexpr bool FILL = MODE == 1;
   int64_t out = FILL ? offsets[q] : 0;
   uint32_t total = 0;
-  for (int64_t w0 = 0; w0 < wpr; w0 += WAVE) {
-    const int64_t w = w0 + lane;
-    uint32_t word = 0u;  // rows >= D never match (an unconstrained query keeps exactly the D table rows)
-    if (w < wpr && w * 32 < D) word = (D - w * 32 >= 32) ? 0xFFFFFFFFu : ((1u << (D - w * 32)) - 1u);
+  for (int64_t w0 = 0; w0 < wpr; w0 += WAVE * VEC) {
+    const int64_t w = w0 + (int64_t)lane * VEC;  // first of this lane's VEC consecutive words
+    uint32_t word[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const int64_t we = w + e;
+      // rows >= D never match (an unconstrained query keeps exactly the D table rows)
+      word[e] = 0u;
+      if (we < wpr && we * 32 < D) word[e] = (D - we * 32 >= 32) ? 0xFFFFFFFFu : ((1u << (D - we * 32)) - 1u);
+    }
     for (int f = 0; f < nfeat; ++f) {
       const int32_t r = __shfl(myrow, f, WAVE);
-      if (r >= 0 && w < wpr) word &= bitmaps[(size_t)r * wpr + w];
+      if (r >= 0 && w < wpr) {
+        const uint32_t *src = bitmaps + (size_t)r * wpr + w;
+        if (VEC == 4) {
+          const u32x4 v = *reinterpret_cast<const u32x4 *>(src);
+          word[0] &= v.x; word[1 % VEC] &= v.y; word[2 % VEC] &= v.z; word[3 % VEC] &= v.w;
+        } else {
+          word[0] &= src[0];
+        }
+      }
     }
-    const uint32_t pc = (uint32_t)__popc(word);
+    uint32_t pc = 0;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) pc += (uint32_t)__popc(word[e]);
     if (MODE == 0) {
       total += pc;
-    } else if (MODE == 2) {
-      uint32_t inc = pc;
-#pragma unroll
-      for (int d = 1; d < WAVE; d <<= 1) {
-        const uint32_t o = __shfl_up(inc, d, WAVE);
-        if (lane >= d) inc += o;
-      }
-      uint32_t p = total + (inc - pc);  // total is wave-uniform here
-      while (word && p < (uint32_t)AS_SLOT) {
-        const int bit = __ffs(word) - 1;
-        rows[q * AS_SLOT + p++] = (int32_t)(w * 32 + bit);
-        word &= word - 1;
-      }
-      total += __shfl(inc, WAVE - 1, WAVE);
     } else {
       // exclusive prefix of the lanes' popcounts: where this lane's rows start
       uint32_t inc = pc;
@@ -68,13 +73,32 @@ __global__ __launch_bounds__(256) void answer_sets_kernel(const uint32_t *__rest
         const uint32_t o = __shfl_up(inc, d, WAVE);
         if (lane >= d) inc += o;
       }
-      int64_t p = out + (inc - pc);
-      while (word) {
-        const int bit = __ffs(word) - 1;
-        rows[p++] = (int32_t)(w * 32 + bit);
-        word &= word - 1;
+      const uint32_t step_total = __shfl(inc, WAVE - 1, WAVE);
+      if (MODE == 2) {
+        uint32_t p = total + (inc - pc);  // total is wave-uniform here
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          uint32_t x = word[e];
+          while (x && p < (uint32_t)AS_SLOT) {
+            const int bit = __ffs(x) - 1;
+            rows[q * AS_SLOT + p++] = (int32_t)((w + e) * 32 + bit);
+            x &= x - 1;
+          }
+        }
+        total += step_total;
+      } else {
+        int64_t p = out + (inc - pc);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          uint32_t x = word[e];
+          while (x) {
+            const int bit = __ffs(x) - 1;
+            rows[p++] = (int32_t)((w + e) * 32 + bit);
+            x &= x - 1;
+          }
+        }
+        out += step_total;
       }
-      out += __shfl(inc, WAVE - 1, WAVE);
     }
   }
   if (MODE == 0) {
@@ -99,6 +123,10 @@ __global__ __launch_bounds__(256) void answer_sets_compact_kernel(const int32_t 
   if (n <= AS_SLOT && lane < n) rows[lo + lane] = tmp[q * AS_SLOT + lane];
 }
 
+static bool answers_vec4(const uint32_t *bitmaps, int64_t wpr) {
+  return (wpr % 4) == 0 && (((uintptr_t)bitmaps) & 15) == 0;
+}
+
 static int answers_check(const uint32_t *bitmaps, int64_t wpr, int64_t D, const int32_t *qrows, int64_t nq,
                          int32_t nfeat, const char *name) {
   QR_CHECK_ARG(nq >= 0 && wpr > 0 && nfeat > 0 && nfeat <= WAVE && D > 0 && D <= wpr * 32,
@@ -115,9 +143,14 @@ QRLSH_EXPORT int qrlsh_answer_sets_count(const uint32_t *bitmaps, int64_t words_
   if (rc != QRLSH_OK) return rc;
   if (nq == 0) return QRLSH_OK;
   QR_CHECK_ARG(sizes_out, "qrlsh_answer_sets_count: null output");
-  QR_LAUNCH("answers_count", (answer_sets_kernel<0>), dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 0,
-            static_cast<hipStream_t>(stream), bitmaps, words_per_row, D, qrows, nq, nfeat, sizes_out,
-            (const int64_t *)nullptr, (int32_t *)nullptr);
+  if (answers_vec4(bitmaps, words_per_row))
+    QR_LAUNCH("answers_count", (answer_sets_kernel<0, 4>), dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 0,
+              static_cast<hipStream_t>(stream), bitmaps, words_per_row, D, qrows, nq, nfeat, sizes_out,
+              (const int64_t *)nullptr, (int32_t *)nullptr);
+  else
+    QR_LAUNCH("answers_count", (answer_sets_kernel<0, 1>), dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 0,
+              static_cast<hipStream_t>(stream), bitmaps, words_per_row, D, qrows, nq, nfeat, sizes_out,
+              (const int64_t *)nullptr, (int32_t *)nullptr);
   QR_LAUNCH_CHECK("qrlsh_answer_sets_count");
   return QRLSH_OK;
 }
@@ -129,9 +162,14 @@ QRLSH_EXPORT int qrlsh_answer_sets_fill(const uint32_t *bitmaps, int64_t words_p
   if (rc != QRLSH_OK) return rc;
   if (nq == 0) return QRLSH_OK;
   QR_CHECK_ARG(offsets, "qrlsh_answer_sets_fill: null offsets");
-  QR_LAUNCH("answers_fill", (answer_sets_kernel<1>), dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 0,
-            static_cast<hipStream_t>(stream), bitmaps, words_per_row, D, qrows, nq, nfeat, (int32_t *)nullptr, offsets,
-            rows_out);
+  if (answers_vec4(bitmaps, words_per_row))
+    QR_LAUNCH("answers_fill", (answer_sets_kernel<1, 4>), dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 0,
+              static_cast<hipStream_t>(stream), bitmaps, words_per_row, D, qrows, nq, nfeat, (int32_t *)nullptr, offsets,
+              rows_out);
+  else
+    QR_LAUNCH("answers_fill", (answer_sets_kernel<1, 1>), dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 0,
+              static_cast<hipStream_t>(stream), bitmaps, words_per_row, D, qrows, nq, nfeat, (int32_t *)nullptr, offsets,
+              rows_out);
   QR_LAUNCH_CHECK("qrlsh_answer_sets_fill");
   return QRLSH_OK;
 }
@@ -145,9 +183,14 @@ QRLSH_EXPORT int qrlsh_answer_sets_sweep(const uint32_t *bitmaps, int64_t words_
   if (rc != QRLSH_OK) return rc;
   if (nq == 0) return QRLSH_OK;
   QR_CHECK_ARG(sizes_out && slots_out, "qrlsh_answer_sets_sweep: null output");
-  QR_LAUNCH("answers_sweep", (answer_sets_kernel<2>), dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 0,
-            static_cast<hipStream_t>(stream), bitmaps, words_per_row, D, qrows, nq, nfeat, sizes_out,
-            (const int64_t *)nullptr, slots_out);
+  if (answers_vec4(bitmaps, words_per_row))
+    QR_LAUNCH("answers_sweep", (answer_sets_kernel<2, 4>), dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 0,
+              static_cast<hipStream_t>(stream), bitmaps, words_per_row, D, qrows, nq, nfeat, sizes_out,
+              (const int64_t *)nullptr, slots_out);
+  else
+    QR_LAUNCH("answers_sweep", (answer_sets_kernel<2, 1>), dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 0,
+              static_cast<hipStream_t>(stream), bitmaps, words_per_row, D, qrows, nq, nfeat, sizes_out,
+              (const int64_t *)nullptr, slots_out);
   QR_LAUNCH_CHECK("qrlsh_answer_sets_sweep");
   return QRLSH_OK;
 }
