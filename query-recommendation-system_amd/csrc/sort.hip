@@ -67,32 +67,48 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const uint64_t 
   const uint64_t *k = keys + (size_t)batch * n;
   const uint32_t *v = vals ? vals + (size_t)batch * n : nullptr;
   const int64_t base = (int64_t)tile * SORT_TILE;
+  // two keys per lane per step (16-byte loads) when the batch base is 16-byte aligned
+  const bool wide = ((((uintptr_t)k) & 15) == 0);
 #pragma unroll
-  for (int i = 0; i < SORT_IPT; ++i) {
-    const int64_t idx = base + (int64_t)i * SORT_THREADS + threadIdx.x;
-    uint32_t dd = 0;
-    if (idx < n) {
-      const uint64_t key = k[idx];
-      uint32_t d;
-      if (SPREAD)
-        d = part_digit<SPREAD>(key, (key == ek && v) ? (int64_t)v[idx] : idx, shift, ek, dmask);
-      else
-        d = digit_of<MIX>(key, shift, fold);
-      if (MIX != SM_OWNER) atomicAdd(&h[d], 1u);
-      dd = d;
+  for (int i = 0; i < SORT_IPT / 2; ++i) {
+    const int64_t idx0 = base + ((int64_t)i * SORT_THREADS + threadIdx.x) * 2;
+    uint64_t kk[2] = {0, 0};
+    if (wide && idx0 + 1 < n) {
+      typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+      const u64x2 t = *reinterpret_cast<const u64x2 *>(k + idx0);
+      kk[0] = t.x;
+      kk[1] = t.y;
+    } else {
+      if (idx0 < n) kk[0] = k[idx0];
+      if (idx0 + 1 < n) kk[1] = k[idx0 + 1];
     }
-    if (MIX == SM_OWNER) {
-      // a handful of distinct digits (ranks): one LDS atomic per digit per wave, not per key
-      const bool valid = idx < n;
-      uint64_t m = __ballot(valid);
 #pragma unroll
-      for (int bit = 0; bit < 8; ++bit) {
-        const bool one = (dd >> bit) & 1u;
-        const uint64_t bal = __ballot(one);
-        m &= one ? bal : ~bal;
+    for (int e = 0; e < 2; ++e) {
+      const int64_t idx = idx0 + e;
+      uint32_t dd = 0;
+      if (idx < n) {
+        const uint64_t key = kk[e];
+        uint32_t d;
+        if (SPREAD)
+          d = part_digit<SPREAD>(key, (key == ek && v) ? (int64_t)v[idx] : idx, shift, ek, dmask);
+        else
+          d = digit_of<MIX>(key, shift, fold);
+        if (MIX != SM_OWNER) atomicAdd(&h[d], 1u);
+        dd = d;
       }
-      const int lane = threadIdx.x & (WAVE - 1);
-      if (valid && (m & ((1ull << lane) - 1ull)) == 0) atomicAdd(&h[dd], (uint32_t)__popcll(m));
+      if (MIX == SM_OWNER) {
+        // a handful of distinct digits (ranks): one LDS atomic per digit per wave, not per key
+        const bool valid = idx < n;
+        uint64_t m = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+          const bool one = (dd >> bit) & 1u;
+          const uint64_t bal = __ballot(one);
+          m &= one ? bal : ~bal;
+        }
+        const int lane = threadIdx.x & (WAVE - 1);
+        if (valid && (m & ((1ull << lane) - 1ull)) == 0) atomicAdd(&h[dd], (uint32_t)__popcll(m));
+      }
     }
   }
   __syncthreads();
