@@ -163,6 +163,39 @@ __global__ __launch_bounds__(256) void minhash_kernel(const int64_t *__restrict_
 // up with the final minimum of its 16-B column chunk), and the row ids of the next batch of G
 // queries are prefetched while the current batch's gathers are in flight.
 constexpr int MH_QPW = 16;  // queries per wave (4 waves -> 64 per workgroup)
+#ifndef MH_CH
+#define MH_CH 4  // table rows gathered per step (independent loads in flight per lane)
+#endif
+
+// value of lane `idx` of every LPR-lane group.  Groups of 16 are DPP rows: one v_mov with
+// row_newbcast instead of an LDS-pipe ds_bpermute plus its wait.
+template <int I> __device__ static inline int row_bcast(int v) {
+  return __builtin_amdgcn_update_dpp(v, v, 0x150 + I, 0xF, 0xF, false);
+}
+template <int LPR> __device__ static inline int group_bcast(int v, int idx, int g) {
+  if constexpr (LPR == 16) {
+    switch (idx) {
+      case 0: return row_bcast<0>(v);
+      case 1: return row_bcast<1>(v);
+      case 2: return row_bcast<2>(v);
+      case 3: return row_bcast<3>(v);
+      case 4: return row_bcast<4>(v);
+      case 5: return row_bcast<5>(v);
+      case 6: return row_bcast<6>(v);
+      case 7: return row_bcast<7>(v);
+      case 8: return row_bcast<8>(v);
+      case 9: return row_bcast<9>(v);
+      case 10: return row_bcast<10>(v);
+      case 11: return row_bcast<11>(v);
+      case 12: return row_bcast<12>(v);
+      case 13: return row_bcast<13>(v);
+      case 14: return row_bcast<14>(v);
+      default: return row_bcast<15>(v);
+    }
+  } else {
+    return __shfl(v, g * LPR + idx, WAVE);
+  }
+}
 
 template <typename TabT, int LPR>
 __global__ __launch_bounds__(256) void minhash_group_kernel(const int64_t *__restrict__ offsets,
@@ -185,6 +218,8 @@ __global__ __launch_bounds__(256) void minhash_group_kernel(const int64_t *__res
   const int col = lig * VEC;
   const bool colok = col < P_stride;
   const bool vec_store = (P % 4) == 0;
+  const char *tbytes = reinterpret_cast<const char *>(tab);
+  const uint32_t row_bytes = (uint32_t)P_stride * sizeof(TabT), col_bytes = (colok ? col : 0) * sizeof(TabT);
 
   // 17 offsets of this wave's 16 queries in one load
   int64_t offs = 0;
@@ -215,17 +250,27 @@ __global__ __launch_bounds__(256) void minhash_group_kernel(const int64_t *__res
     }
     VecT acc = TabVec<TabT>::init();
     int my = my_cur;
+    // min is idempotent: slots past the end of a (shorter) answer set re-read the query's first
+    // row instead of being predicated off, so the MH_CH gathers of a step are independent
+    // loads in flight together rather than MH_CH exec-masked load -> wait -> min round trips.
+    const int d_first = group_bcast<LPR>(my, 0, g);
     for (int base = 0; __any(base < n_cur); base += LPR) {
-      if (base > 0) my = (base + lig < n_cur) ? rows[lo_cur + base + lig] : 0;
-      const int cnt = min(LPR, n_cur - base);
+      const int my_after = (base + LPR + lig < n_cur) ? rows[lo_cur + base + LPR + lig] : 0;
 #pragma unroll
-      for (int i = 0; i < LPR; ++i) {
-        const int d = __shfl(my, g * LPR + i, WAVE);
-        if (i < cnt && colok) {
-          const VecT v = *reinterpret_cast<const VecT *>(tab + (size_t)d * P_stride + col);
-          acc = __builtin_elementwise_min(acc, v);
+      for (int sub = 0; sub < LPR; sub += MH_CH) {
+        if (sub > 0 && !__any(base + sub < n_cur)) break;  // wave-uniform
+        VecT v[MH_CH];
+#pragma unroll
+        for (int j = 0; j < MH_CH; ++j) {
+          const int ds = group_bcast<LPR>(my, sub + j, g);
+          const int d = (base + sub + j < n_cur) ? ds : d_first;
+          // 32-bit byte offset from a uniform base (table < 4 GiB, d < 2^24: checked by the host)
+          v[j] = *reinterpret_cast<const VecT *>(tbytes + (__umul24((uint32_t)d, row_bytes) + col_bytes));
         }
+#pragma unroll
+        for (int j = 0; j < MH_CH; ++j) acc = __builtin_elementwise_min(acc, v[j]);
       }
+      my = my_after;
     }
     if (q < nq) {
       int64_t nrm = 0;
@@ -303,14 +348,14 @@ static int pick_qpb(int P) {
 
 template <typename TabT>
 static int launch_minhash(const int64_t *offsets, const int32_t *rows, int64_t nq, const void *perm_t, int P,
-                          int P_stride, int32_t *sig, uint16_t *sig16, int64_t *norm2, uint64_t *keys, int b, int r,
-                          hipStream_t st) {
+                          int P_stride, int D, int32_t *sig, uint16_t *sig16, int64_t *norm2, uint64_t *keys, int b,
+                          int r, hipStream_t st) {
   constexpr int VEC = 16 / sizeof(TabT);
   const int lanes = (P_stride + VEC - 1) / VEC;
   const TabT *tab = static_cast<const TabT *>(perm_t);
   const dim3 block(256);
   const size_t smem_group = keys ? (size_t)64 * (P + 2) * 2 : 0;
-  if (lanes <= 64 && smem_group <= 65536) {
+  if (lanes <= 64 && smem_group <= 65536 && D <= (1 << 24) && (size_t)D * P_stride * sizeof(TabT) < (1ull << 32)) {
     // group-per-query kernel: 64 queries per workgroup
     const dim3 grid((unsigned)ceil_div64(nq, 64));
 #define QR_MHG(LPR_)                                                                                            \
@@ -360,10 +405,10 @@ QRLSH_EXPORT int qrlsh_minhash(const int64_t *offsets, const int32_t *rows, int6
   if (nq == 0) return QRLSH_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (perm_dtype == QRLSH_PERM_U16)
-    return launch_minhash<uint16_t>(offsets, rows, nq, perm_t, P, P_stride, sig_out, sig16_out, norm2_out, keys_out, b,
-                                    r, st);
-  return launch_minhash<int32_t>(offsets, rows, nq, perm_t, P, P_stride, sig_out, nullptr, norm2_out, keys_out, b, r,
-                                 st);
+    return launch_minhash<uint16_t>(offsets, rows, nq, perm_t, P, P_stride, D, sig_out, sig16_out, norm2_out, keys_out,
+                                    b, r, st);
+  return launch_minhash<int32_t>(offsets, rows, nq, perm_t, P, P_stride, D, sig_out, nullptr, norm2_out, keys_out, b,
+                                 r, st);
 }
 
 QRLSH_EXPORT int qrlsh_band_keys(const int32_t *sig, int64_t nq, int32_t P, int32_t b, uint64_t *keys_out,

@@ -242,6 +242,116 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const uint64
   }
 }
 
+// Keys-only scatter with LDS staging: after ranking, the tile is laid out in LDS in its
+// sorted-by-digit order and written out by consecutive lanes, so a store instruction covers a few
+// contiguous runs instead of up to 64 unrelated lines.  Same inputs / outputs as
+// sort_scatter_kernel<MODE, false, false>; 37 KB of LDS keeps the 4 workgroups per CU that the
+// register budget allows anyway.
+template <int MODE>
+__global__ __launch_bounds__(SORT_THREADS, 4) void sort_scatter_staged_kernel(const uint64_t *__restrict__ keys_in,
+                                                                           uint64_t *__restrict__ keys_out, int64_t n,
+                                                                           int ntiles, int shift,
+                                                                           const uint32_t *__restrict__ goff,
+                                                                           const uint32_t *__restrict__ rtot,
+                                                                           uint32_t fold) {
+  __shared__ uint32_t cnt[SORT_THREADS / WAVE][RADIX];
+  __shared__ uint32_t dsum[SORT_THREADS / WAVE];
+  __shared__ uint32_t lsum[SORT_THREADS / WAVE];
+  __shared__ uint32_t gdelta[RADIX];
+  __shared__ uint64_t skey[SORT_TILE];
+  const int tile = xcd_tile(blockIdx.x, ntiles), batch = blockIdx.y;
+  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < SORT_THREADS / WAVE; ++i) cnt[i][threadIdx.x] = 0;
+  __syncthreads();
+  const size_t boff = (size_t)batch * n;
+  const int64_t tbase = (int64_t)tile * SORT_TILE;
+  const int64_t wbase = tbase + (int64_t)w * (WAVE * SORT_IPT);
+  uint64_t key[SORT_IPT];
+  uint32_t dr[SORT_IPT];
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int k = 0; k < SORT_IPT; ++k) {
+    const int64_t idx = wbase + (int64_t)k * WAVE + lane;
+    key[k] = idx < n ? keys_in[boff + idx] : 0;
+  }
+#pragma unroll
+  for (int k = 0; k < SORT_IPT; ++k) {
+    const int64_t idx = wbase + (int64_t)k * WAVE + lane;
+    const bool valid = idx < n;
+    const uint32_t d = digit_of<MODE>(key[k], shift, fold);
+    uint64_t m = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+      const bool one = (d >> bit) & 1u;
+      const uint64_t bal = __ballot(one);
+      m &= one ? bal : ~bal;
+    }
+    const uint32_t below = (uint32_t)__popcll(m & lt_mask);
+    uint32_t prev = 0;
+    if (valid) {
+      prev = cnt[w][d];
+      if (below == 0) cnt[w][d] = prev + (uint32_t)__popcll(m);
+    }
+    dr[k] = (d << 16) | (prev + below);
+  }
+  __syncthreads();
+  {
+    const int d = threadIdx.x;
+    // digit base (global) = exclusive prefix of the 256 row totals; tile-local start = exclusive
+    // prefix of this tile's 256 digit counts
+    const uint32_t tot = rtot[(size_t)batch * RADIX + d];
+    uint32_t tc = 0;
+#pragma unroll
+    for (int i = 0; i < SORT_THREADS / WAVE; ++i) tc += cnt[i][d];
+    uint32_t inc = tot, linc = tc;
+#pragma unroll
+    for (int k = 1; k < WAVE; k <<= 1) {
+      const uint32_t o = __shfl_up(inc, k, WAVE), lo = __shfl_up(linc, k, WAVE);
+      if (lane >= k) {
+        inc += o;
+        linc += lo;
+      }
+    }
+    if (lane == WAVE - 1) {
+      dsum[w] = inc;
+      lsum[w] = linc;
+    }
+    __syncthreads();
+    uint32_t dbase = inc - tot, lstart = linc - tc;
+#pragma unroll
+    for (int k = 0; k < SORT_THREADS / WAVE; ++k)
+      if (k < w) {
+        dbase += dsum[k];
+        lstart += lsum[k];
+      }
+    gdelta[d] = dbase + goff[((size_t)batch * RADIX + d) * ntiles + tile] - lstart;
+    uint32_t run = lstart;
+#pragma unroll
+    for (int i = 0; i < SORT_THREADS / WAVE; ++i) {
+      const uint32_t c = cnt[i][d];
+      cnt[i][d] = run;  // tile-local position of wave i's first key with digit d
+      run += c;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < SORT_IPT; ++k) {
+    const int64_t idx = wbase + (int64_t)k * WAVE + lane;
+    if (idx < n) skey[cnt[w][dr[k] >> 16] + (dr[k] & 0xFFFFu)] = key[k];
+  }
+  __syncthreads();
+  const int ntile = (int)min((int64_t)SORT_TILE, n - tbase);
+#pragma unroll
+  for (int k = 0; k < SORT_IPT; ++k) {
+    const int p = k * SORT_THREADS + threadIdx.x;
+    if (p < ntile) {
+      const uint64_t kk = skey[p];
+      keys_out[boff + gdelta[digit_of<MODE>(kk, shift, fold)] + (uint32_t)p] = kk;
+    }
+  }
+}
+
 QRLSH_EXPORT size_t qrlsh_sort_workspace_bytes(int64_t n, int32_t nbatch) {
   if (n <= 0 || nbatch <= 0) return 16;
   const int64_t ntiles = ceil_div64(n, SORT_TILE);
@@ -261,7 +371,10 @@ static int sort_passes(uint64_t *ka, uint64_t *kb, uint32_t *va, uint32_t *vb, i
     uint32_t *vin = cur ? vb : va, *vout = cur ? va : vb;
     QR_LAUNCH("sort_hist", (sort_hist_kernel<MIX>), grid, block, 0, st, kin, n, ntiles, shift, ghist, (uint64_t)0, fold);
     QR_LAUNCH("sort_rowscan", sort_rowscan_kernel, dim3(RADIX, nbatch), dim3(256), 0, st, ghist, ntiles, rtot);
-    if (!has_val)
+    if (!has_val && (MIX == SM_PLAIN || MIX == SM_FOLD))
+      QR_LAUNCH("sort_scatter_k", (sort_scatter_staged_kernel<MIX>), grid, block, 0, st, kin, kout, n, ntiles, shift,
+                ghist, rtot, fold);
+    else if (!has_val)
       QR_LAUNCH("sort_scatter_k", (sort_scatter_kernel<MIX, false, false>), grid, block, 0, st, kin, vin, kout, vout, n,
                          ntiles, shift, ghist, rtot, (uint64_t)0, fold);
     else if (iota && shift == bit_lo)

@@ -21,6 +21,9 @@ def main():
     ap.add_argument("--drows", type=int, default=32768)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--stage", default="all")
+    ap.add_argument("--no-keys", action="store_true")
+    ap.add_argument("--no-norm", action="store_true")
+    ap.add_argument("--wide-sig", action="store_true", help="int32 signature rows instead of compact uint16")
     a = ap.parse_args()
     dev = "cuda"
     off, rows = qrlsh.synth_csr(a.nq, a.drows, seed=0, device=dev)
@@ -32,7 +35,8 @@ def main():
         if a.stage == "all":
             pipeline.query_similarities(off, rows, table, a.bands, K)
         elif a.stage == "minhash":
-            ops.minhash(off, rows, table, b=a.bands)
+            ops.minhash(off, rows, table, b=None if a.no_keys else a.bands, want_norm=not a.no_norm,
+                        compact=not a.wide_sig and ops.can_compact(table))
         elif a.stage == "bucket":
             _, _, keys = ops.minhash(off, rows, table, b=a.bands)
             ops.emit_pairs_any(keys, r)
