@@ -58,7 +58,7 @@ def algorithmic_bytes_per_step(w):
     sb = w["sig_bytes"]
     rec = b * w["nq_sorted"]                      # (band, query) records this rank buckets
     ib = max(1, (w["nq_total"] - 1).bit_length())
-    pair_passes = -(-2 * ib // 8)
+    pair_passes = -(-ib // 8)                     # pairs are grouped by i only; rows are finished in LDS
     edge_passes = -(-(ib + 11) // 8)
     out = {
         # CSR in (4 B/row id + 8 B offset); signature row, fused band keys and norm out
@@ -70,8 +70,9 @@ def algorithmic_bytes_per_step(w):
         # keys-only LSD passes: pair words, then directed edge keys
         "sort_scatter_k": 16 * (pair_passes * em + edge_passes * 2 * un),
         "sort_hist": 8 * (rec + pair_passes * em + edge_passes * 2 * un),
-        "unique_count": 8 * em,
-        "unique_fill": 8 * em + 8 * un,
+        # rows de-duplicated and ordered in LDS: emitted words in, distinct words out; then the gaps closed
+        "row_unique": 8 * em + 8 * un,
+        "row_unique_gather": 16 * un,
         # two signature rows + pair word in; score + two edge keys out
         "score_pairs": (2 * sb * P + 8 + 4 + 16) * un,
         "topk_count": 8 * 2 * un,

@@ -144,6 +144,20 @@ int qrlsh_unique_count(const uint64_t *sorted, int64_t n, void *workspace, size_
 int qrlsh_unique_fill(const uint64_t *sorted, int64_t n, const void *workspace, uint64_t *out,
                       void *stream);
 
+/* Sorted unique pairs from pairs that are only GROUPED BY i (qrlsh_sort_u64 over bits [32, 32 + id_bits)
+ * of the emitted i << 32 | j words: about half the passes of the full (i, j) sort): every row -- the
+ * pairs of one i, tens of words -- is de-duplicated (hash set) and ordered by j in LDS.  Replaces the Python set of
+ * lsh.py:41,53 like qrlsh_unique_*, same result.  count: tmp is scratch of n words; leaves {number of
+ * unique pairs, overflow flag} in total_overflow_out[2] (device uint64 x2); overflow != 0 means one i
+ * has more than ~1024 emitted pairs past a 2048-word chunk boundary: ignore the total and use the general
+ * path (full qrlsh_sort_u64 + qrlsh_unique_*) on the same words.  fill follows a count on the same
+ * tmp / workspace and writes exactly `total` words, ascending.
+ */
+size_t qrlsh_row_unique_workspace_bytes(int64_t n);
+int qrlsh_row_unique_count(const uint64_t *grouped, int64_t n, uint64_t *tmp, void *workspace,
+                           size_t workspace_bytes, uint64_t *total_overflow_out, void *stream);
+int qrlsh_row_unique_fill(const uint64_t *tmp, int64_t n, const void *workspace, uint64_t *out, void *stream);
+
 /* ---- a5: pair scoring ------------------------------------------------------------
  * Replaces the cosine of recommender.py:203-204 for one candidate pair:
  *     np.around(cosine_similarity([sig_i, sig_j])[0][1], 3)

@@ -319,6 +319,245 @@ QRLSH_EXPORT int qrlsh_unique_fill(const uint64_t *sorted, int64_t n, const void
   return QRLSH_OK;
 }
 
+// ---- a3 tail, fast form: sorted unique pairs from pairs GROUPED BY i ---------------------------
+// The emitted pairs carry every candidate once per band it collides in (5.5x on the config-2
+// workload), and a full (i, j) radix sort of all of them only to drop the repeats is the
+// largest block of sort passes in the pipeline.  Here the pairs are sorted on i's bits only
+// (ceil(id_bits / 8) passes instead of ceil(2 id_bits / 8)); a row (all pairs of one i) is then
+// a short run -- tens of words -- that is de-duplicated and ordered by j inside LDS:
+//   1. the row's own span of an LDS array serves as an open-addressing hash set of its j values
+//      (as many slots as the row has words; ds_cmpst claims a slot or finds the value present);
+//   2. a workgroup prefix sum over the occupied slots packs the distinct values, row by row;
+//   3. the place of a distinct value is the number of smaller ones in its (now short) packed row.
+//
+// A workgroup owns the rows whose first word lies in its RD_C-word chunk; it loads RD_CAP words
+// beyond the chunk so that the last owned row is complete (a longer overhang sets the overflow
+// flag: the caller then uses the general sort + qrlsh_unique path).  The kept words of a
+// workgroup are written, in order, into `tmp` starting at its first owned word (owned ranges
+// tile the input, so these never overlap); per-workgroup counts are scanned and a second small
+// kernel closes the gaps.
+constexpr int RD_THREADS = 512;
+constexpr int RD_C = 2048;
+constexpr int RD_CAP = 1024;
+constexpr int RD_IMG = RD_C + RD_CAP;
+constexpr int RD_PER = RD_IMG / RD_THREADS;
+constexpr uint32_t RD_EMPTY = 0xFFFFFFFFu;  // never a j (ids are non-negative int32)
+
+__global__ __launch_bounds__(RD_THREADS) void row_unique_kernel(const uint64_t *__restrict__ in, int64_t n,
+                                                                uint64_t *__restrict__ tmp,
+                                                                uint64_t *__restrict__ counts,
+                                                                uint64_t *__restrict__ starts,
+                                                                uint64_t *__restrict__ overflow) {
+  __shared__ uint32_t lo[RD_IMG];    // j of every word; later: the packed distinct values
+  __shared__ uint32_t tab[RD_IMG];   // hash sets, one per owned row, over the row's own span
+  __shared__ uint16_t rs[RD_IMG];    // row start + 1 of the row a word belongs to, 0 = row began before the image
+  __shared__ uint16_t re[RD_IMG];    // at a row's start: one past its last word
+  __shared__ uint16_t pre[RD_IMG + 1];  // occupied slots before position p
+  __shared__ uint16_t crow[RD_IMG];  // row start of every packed value
+  __shared__ uint32_t wsum[RD_THREADS / WAVE];
+  __shared__ uint32_t h0s, tail_open;
+  const int t = threadIdx.x, lane = t & (WAVE - 1), w = t >> 6;
+  const int64_t c0 = (int64_t)blockIdx.x * RD_C;
+  const int m = (int)min((int64_t)RD_IMG, n - c0);
+  const int mc = min(RD_C, m);
+  if (t == 0) {
+    h0s = 0xFFFFFFFFu;
+    tail_open = 0;
+  }
+  __syncthreads();
+  // load; a word whose i differs from its predecessor's starts a row (i itself is not kept in LDS:
+  // the output step re-reads it, the lines are still in L2)
+  {
+    uint64_t x[RD_PER], xp[RD_PER];  // all global loads of the workgroup are issued before the first use
+#pragma unroll
+    for (int k = 0; k < RD_PER; ++k) {
+      const int p = k * RD_THREADS + t;
+      x[k] = p < m ? in[c0 + p] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < RD_PER; ++k) {
+      const int p = k * RD_THREADS + t;
+      xp[k] = (lane == 0 && p < m && c0 + p > 0) ? in[c0 + p - 1] : 0;
+    }
+    const bool more = t == 0 && c0 + m < n;   // does the last word's row go on past the image?
+    const uint64_t xlast = more ? in[c0 + m - 1] : 0, xnext = more ? in[c0 + m] : 1ull << 32;
+#pragma unroll
+    for (int k = 0; k < RD_PER; ++k) {
+      const int p = k * RD_THREADS + t;
+      const uint32_t h = (uint32_t)(x[k] >> 32);
+      const uint32_t ph = __shfl_up(h, 1, WAVE);
+      if (p < m) {
+        lo[p] = (uint32_t)x[k];
+        tab[p] = RD_EMPTY;
+        const bool head = lane == 0 ? (c0 + p == 0 || (uint32_t)(xp[k] >> 32) != h) : ph != h;
+        rs[p] = head ? (uint16_t)(p + 1) : (uint16_t)0;
+      }
+    }
+    if (more && (xlast >> 32) == (xnext >> 32)) tail_open = 1;
+  }
+  __syncthreads();
+
+  // row starts: running maximum of (head position + 1), blocked layout (RD_PER consecutive words per thread)
+  const int b0 = t * RD_PER;
+  {
+    uint32_t run = 0;
+    uint16_t loc[RD_PER];
+#pragma unroll
+    for (int k = 0; k < RD_PER; ++k) {
+      const int p = b0 + k;
+      if (p < m) run = max(run, (uint32_t)rs[p]);
+      loc[k] = (uint16_t)run;
+    }
+    uint32_t inc = run;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+      const uint32_t o = __shfl_up(inc, d, WAVE);
+      if (lane >= d) inc = max(inc, o);
+    }
+    if (lane == WAVE - 1) wsum[w] = inc;
+    __syncthreads();
+    uint32_t excl = __shfl_up(inc, 1, WAVE);
+    if (lane == 0) excl = 0;
+    for (int k = 0; k < w; ++k) excl = max(excl, wsum[k]);
+#pragma unroll
+    for (int k = 0; k < RD_PER; ++k) {
+      const int p = b0 + k;
+      if (p < m) rs[p] = (uint16_t)max((uint32_t)loc[k], excl);
+    }
+  }
+  __syncthreads();
+  for (int p = t; p < m; p += RD_THREADS) {
+    const uint32_t s1 = rs[p];
+    if (!s1) continue;
+    if (s1 == (uint32_t)p + 1u && p < mc) atomicMin(&h0s, (uint32_t)p);
+    const bool last = p + 1 == m;
+    if (last || rs[p + 1] == (uint16_t)(p + 2)) re[s1 - 1] = (uint16_t)(p + 1);
+    if (last && (int)s1 - 1 < mc && tail_open) atomicOr((unsigned long long *)overflow, 1ull);
+  }
+  __syncthreads();
+
+  // 1. hash-set insert of every owned word into its row's span of tab
+  for (int p = t; p < m; p += RD_THREADS) {
+    const uint32_t s1 = rs[p];
+    if (!s1 || (int)s1 - 1 >= mc) continue;
+    const uint32_t s = s1 - 1, e = re[s], len = e - s, v = lo[p];
+    uint32_t slot = s + __umulhi(v * 0x9E3779B1u, len);
+    for (;;) {  // at most len probes: the row has len slots and at most len distinct values
+      const uint32_t old = atomicCAS(&tab[slot], RD_EMPTY, v);
+      if (old == RD_EMPTY || old == v) break;
+      slot = slot + 1 == e ? s : slot + 1;
+    }
+  }
+  __syncthreads();
+  // 2. exclusive prefix sum over the occupied slots; pack the distinct values (lo is free now)
+  uint32_t total;
+  {
+    uint32_t sum = 0, val[RD_PER];
+#pragma unroll
+    for (int k = 0; k < RD_PER; ++k) {
+      const int p = b0 + k;
+      val[k] = p < m ? tab[p] : RD_EMPTY;
+      sum += val[k] != RD_EMPTY;
+    }
+    uint32_t inc = sum;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+      const uint32_t o = __shfl_up(inc, d, WAVE);
+      if (lane >= d) inc += o;
+    }
+    __syncthreads();  // every wave is done with wsum (row starts) and with lo
+    if (lane == WAVE - 1) wsum[w] = inc;
+    __syncthreads();
+    uint32_t run = inc - sum;
+    total = 0;
+    for (int k = 0; k < RD_THREADS / WAVE; ++k) {
+      if (k < w) run += wsum[k];
+      total += wsum[k];
+    }
+#pragma unroll
+    for (int k = 0; k < RD_PER; ++k) {
+      const int p = b0 + k;
+      if (p <= m) pre[p] = (uint16_t)run;   // p == m: the grand total (one thread reaches it)
+      if (val[k] != RD_EMPTY) {
+        lo[run] = val[k];
+        crow[run] = (uint16_t)(rs[p] - 1);
+        ++run;
+      }
+    }
+    if (t == RD_THREADS - 1) pre[m] = (uint16_t)total;
+  }
+  __syncthreads();
+  // 3. place of every distinct value inside its packed row; write out
+  const uint32_t h0 = h0s == 0xFFFFFFFFu ? 0u : h0s;
+  uint64_t *dst = tmp + c0 + h0;
+  for (uint32_t k = t; k < total; k += RD_THREADS) {
+    const uint32_t s = crow[k], cs = pre[s], ce = pre[re[s]], v = lo[k];
+    uint32_t r = 0;
+    for (uint32_t q = cs; q < ce; ++q) r += lo[q] < v;
+    dst[cs + r] = (in[c0 + s] & 0xFFFFFFFF00000000ull) | v;
+  }
+  if (t == 0) {
+    counts[blockIdx.x] = total;
+    starts[blockIdx.x] = (uint64_t)(c0 + h0);
+  }
+}
+
+// close the gaps: workgroup g copies its counts[g] kept words from tmp[starts[g]..] to out[offs[g]..]
+__global__ __launch_bounds__(RD_THREADS) void row_unique_gather_kernel(const uint64_t *__restrict__ tmp,
+                                                                       const uint64_t *__restrict__ offs,
+                                                                       const uint64_t *__restrict__ starts,
+                                                                       uint64_t *__restrict__ out) {
+  const uint64_t o0 = offs[blockIdx.x], cnt = offs[blockIdx.x + 1] - o0;
+  const uint64_t *src = tmp + starts[blockIdx.x];
+  for (uint32_t k = threadIdx.x; k < cnt; k += RD_THREADS) out[o0 + k] = src[k];
+}
+
+QRLSH_EXPORT size_t qrlsh_row_unique_workspace_bytes(int64_t n) {
+  const int64_t nblk = n > 0 ? ceil_div64(n, RD_C) : 0;
+  return (size_t)(2 * (nblk + 1)) * sizeof(uint64_t);
+}
+
+QRLSH_EXPORT int qrlsh_row_unique_count(const uint64_t *grouped, int64_t n, uint64_t *tmp, void *workspace,
+                                        size_t workspace_bytes, uint64_t *total_overflow_out, void *stream) {
+  QR_CHECK_ARG(n >= 0 && total_overflow_out, "qrlsh_row_unique_count: bad arguments");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(total_overflow_out, 0, 2 * sizeof(uint64_t), st) != hipSuccess) {
+    qrlsh_set_error("qrlsh_row_unique_count: hipMemsetAsync failed");
+    return QRLSH_EHIP;
+  }
+  if (n == 0) return QRLSH_OK;
+  QR_CHECK_ARG(grouped && tmp && workspace, "qrlsh_row_unique_count: null pointer");
+  if (workspace_bytes < qrlsh_row_unique_workspace_bytes(n)) {
+    qrlsh_set_error("qrlsh_row_unique_count: workspace %zu < %zu bytes", workspace_bytes,
+                    qrlsh_row_unique_workspace_bytes(n));
+    return QRLSH_EWORKSPACE;
+  }
+  const int64_t nblk = ceil_div64(n, RD_C);
+  uint64_t *counts = static_cast<uint64_t *>(workspace), *starts = counts + (nblk + 1);
+  if (hipMemsetAsync(counts + nblk, 0, sizeof(uint64_t), st) != hipSuccess) {
+    qrlsh_set_error("qrlsh_row_unique_count: hipMemsetAsync failed");
+    return QRLSH_EHIP;
+  }
+  QR_LAUNCH("row_unique", row_unique_kernel, dim3((unsigned)nblk), dim3(RD_THREADS), 0, st, grouped, n, tmp, counts,
+            starts, total_overflow_out + 1);
+  QR_LAUNCH("scan_blocks", scan_u64_kernel, dim3(1), dim3(1024), 0, st, counts, nblk + 1, total_overflow_out);
+  QR_LAUNCH_CHECK("qrlsh_row_unique_count");
+  return QRLSH_OK;
+}
+
+QRLSH_EXPORT int qrlsh_row_unique_fill(const uint64_t *tmp, int64_t n, const void *workspace, uint64_t *out,
+                                       void *stream) {
+  QR_CHECK_ARG(n >= 0, "qrlsh_row_unique_fill: bad n");
+  if (n == 0) return QRLSH_OK;
+  QR_CHECK_ARG(tmp && workspace && out, "qrlsh_row_unique_fill: null pointer");
+  const int64_t nblk = ceil_div64(n, RD_C);
+  const uint64_t *offs = static_cast<const uint64_t *>(workspace), *starts = offs + (nblk + 1);
+  QR_LAUNCH("row_unique_gather", row_unique_gather_kernel, dim3((unsigned)nblk), dim3(RD_THREADS), 0,
+            static_cast<hipStream_t>(stream), tmp, offs, starts, out);
+  QR_LAUNCH_CHECK("qrlsh_row_unique_fill");
+  return QRLSH_OK;
+}
+
 QRLSH_EXPORT int qrlsh_topk_count(const uint64_t *sorted_edges, int64_t n_edges, int32_t K, int32_t id_bits,
                                   void *workspace, size_t workspace_bytes, uint64_t *total_out, void *stream) {
   // id_bits == 0 selects the wide-id edge format (src << 11 | inv, dst as payload)

@@ -48,6 +48,9 @@ SIGNATURES = {
     "qrlsh_bucket_pairs_count": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp, _vp]),
     "qrlsh_bucket_pairs_fill": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "qrlsh_compact_workspace_bytes": (_sz, [_i64]),
+    "qrlsh_row_unique_workspace_bytes": (_sz, [_i64]),
+    "qrlsh_row_unique_count": (ctypes.c_int, [_vp, _i64, _vp, _vp, _sz, _vp, _vp]),
+    "qrlsh_row_unique_fill": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp]),
     "qrlsh_unique_count": (ctypes.c_int, [_vp, _i64, _vp, _sz, _vp, _vp]),
     "qrlsh_unique_fill": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp]),
     "qrlsh_row_norms": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp]),

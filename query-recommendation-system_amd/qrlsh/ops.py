@@ -269,6 +269,44 @@ def sort_pairs(pairs, nq):
     return p
 
 
+def group_pairs_by_i(pairs, nq):
+    """pairs i<<32|j ordered by i only (j in arbitrary order inside a row): ceil(id_bits / 8) passes"""
+    p, _ = sort_u64(pairs, None, 32, 32 + id_bits_for(nq))
+    return p
+
+
+def row_unique(grouped):
+    """Sorted unique pairs from pairs grouped by i (group_pairs_by_i); None when a row is too long
+    for the LDS image (skewed data) -- use unique_sorted(sort_pairs(...)) then."""
+    lib = _lib.load()
+    _need(grouped, torch.int64, "grouped", 1)
+    n = grouped.numel()
+    if n == 0:
+        return grouped
+    dev = grouped.device
+    tmp = torch.empty_like(grouped)
+    ws = _ws(lib.qrlsh_row_unique_workspace_bytes(n), dev)
+    tot = torch.empty(2, dtype=torch.int64, device=dev)
+    _lib.check(lib.qrlsh_row_unique_count(_ptr(grouped), n, _ptr(tmp), _ptr(ws), ws.numel(), _ptr(tot), _stream()))
+    total, overflow = tot.tolist()
+    if overflow:
+        return None
+    out = torch.empty((total,), dtype=torch.int64, device=dev)
+    _lib.check(lib.qrlsh_row_unique_fill(_ptr(tmp), n, _ptr(ws), _ptr(out), _stream()))
+    return out
+
+
+def unique_pairs(emitted, nq, stats=None):
+    """the Python set of lsh.py:41,53: sorted unique words of the emitted pairs (consumed)"""
+    grouped = group_pairs_by_i(emitted, nq)
+    pairs = row_unique(grouped)
+    if stats is not None:
+        stats["dedup_path"] = "rows-in-lds" if pairs is not None else "full-sort"
+    if pairs is None:
+        pairs = unique_sorted(sort_pairs(grouped, nq))
+    return pairs
+
+
 def part_bits_for(n):
     """T = bits of the hash partition of the fast bucket path: parts of <= ~4400 records on
     average (the LDS image holds 6144), at least 8, at most 16."""
@@ -357,7 +395,7 @@ def candidate_pairs(keys, r, stats=None, sig=None):
         stats["emitted_pairs"] = int(emitted.numel())
     if emitted.numel() == 0:
         return emitted
-    pairs = unique_sorted(sort_pairs(emitted, nq))
+    pairs = unique_pairs(emitted, nq, stats)
     if r > 4:
         pairs = drop_unverified(sig, b, pairs, stats)
     return pairs

@@ -137,6 +137,60 @@ def test_mix_sort_groups_equal_keys():
 
 
 # ---------------------------------------------------------------------------- a3
+def _rows_case(rng, nq, lens, jmax, dup):
+    """pairs grouped by i (rows in ascending i, j shuffled inside a row, each j repeated up to `dup` times)"""
+    out = []
+    for i, ln in enumerate(lens):
+        if ln == 0:
+            continue
+        base = rng.integers(i + 1, jmax, size=max(1, ln // dup + 1))
+        js = rng.choice(base, size=ln)
+        out.append((np.uint64(i) << np.uint64(32)) | js.astype(np.uint64))
+    return np.concatenate(out) if out else np.zeros(0, np.uint64)
+
+
+@pytest.mark.parametrize("id_bits", [20, 32])
+@pytest.mark.parametrize("case", ["short", "mixed", "chunk_edges", "one_row", "tiny", "empty"])
+def test_row_unique_equals_sorted_set(case, id_bits):
+    """qrlsh_row_unique_* (rows de-duplicated and ordered in LDS) == np.unique of the same words"""
+    rng = np.random.default_rng(11)
+    if case == "short":
+        lens = rng.poisson(17, size=20000)
+    elif case == "mixed":
+        lens = rng.poisson(12, size=8000)
+        lens[rng.integers(0, 8000, size=40)] = rng.integers(300, 1000, size=40)
+    elif case == "chunk_edges":          # rows of exactly the chunk size and its neighbours, back to back
+        lens = np.array([1024, 1, 1023, 1024, 1024, 2, 1020, 5, 1000, 1024, 23, 1024, 1] * 3)
+    elif case == "one_row":
+        lens = np.array([900])
+    elif case == "tiny":
+        lens = np.array([1, 0, 2, 1])
+    else:
+        lens = np.array([], dtype=np.int64)
+    words = _rows_case(rng, len(lens), lens, 1 << min(id_bits, 31), dup=4)
+    got = ops.row_unique(dev(words.view(np.int64)))
+    assert got is not None
+    assert np.array_equal(u64(got), np.unique(words))
+
+
+def test_row_unique_reports_overflow_and_unique_pairs_falls_back():
+    rng = np.random.default_rng(12)
+    lens = rng.poisson(10, size=3000)
+    lens[1500] = 6000                     # one i with far more emitted pairs than the LDS image holds
+    words = _rows_case(rng, len(lens), lens, 1 << 20, dup=3)
+    assert ops.row_unique(dev(words.view(np.int64))) is None
+    shuffled = words[rng.permutation(len(words))]
+    stats = {}
+    got = ops.unique_pairs(dev(shuffled.view(np.int64)), 1 << 20, stats)
+    assert stats["dedup_path"] == "full-sort"
+    assert np.array_equal(u64(got), np.unique(words))
+    stats = {}
+    lens[1500] = 10
+    words = _rows_case(rng, len(lens), lens, 1 << 20, dup=3)
+    got = ops.unique_pairs(dev(words[rng.permutation(len(words))].view(np.int64)), 1 << 20, stats)
+    assert stats["dedup_path"] == "rows-in-lds" and np.array_equal(u64(got), np.unique(words))
+
+
 @pytest.mark.parametrize("name", FULL + PIECES)
 def test_candidates_match_reference_golden(name):
     from lsh import LSH
