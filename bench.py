@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="queries in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="OpenMP threads of the CPU baseline (box share: 16/GPU)")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--prof-every", type=int, default=5,
+                    help="bracket the kernels of every Nth timed step with HIP events (1 = every step; the events "
+                         "serialise back-to-back launches and cost ~10 %% of a step when recorded on all of them)")
     ap.add_argument("--exchange", default="all_to_all", choices=["all_to_all", "all_gather"],
                     help="bucket-id exchange of the sharded path (N > 1)")
     ap.add_argument("--force-dist", action="store_true", help="run the sharded driver even with one rank (testing)")
@@ -149,10 +152,16 @@ def main():
     for _ in range(args.warmup):
         res = step()
     sync()
+    every = max(1, args.prof_every)
+    prof_steps = 0
     if not args.no_prof:
         _lib.prof_enable(True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if not args.no_prof:
+            sampled = i % every == 0
+            _lib.prof_pause(not sampled)
+            prof_steps += sampled
         res = step()
     sync()
     elapsed = time.perf_counter() - t0
@@ -181,11 +190,11 @@ def main():
         ab = algorithmic_bytes_per_step(w)
         traffic, traffic_src = load_traffic()
         kernels = {}
-        for name, (cnt_, ms) in prof.items():
-            k = {"launches_per_step": cnt_ / args.steps, "ms_per_step": ms / args.steps, "avg_ms": ms / cnt_}
+        for name, (cnt_, ms) in prof.items():   # summed over the prof_steps sampled steps of the timed region
+            k = {"launches_per_step": cnt_ / prof_steps, "ms_per_step": ms / prof_steps, "avg_ms": ms / cnt_}
             if name in ab and ms > 0:
                 k["algorithmic_bytes_per_step"] = ab[name]
-                k["algorithmic_GBps"] = round(ab[name] / (ms / args.steps * 1e-3) / 1e9, 1)
+                k["algorithmic_GBps"] = round(ab[name] / (ms / prof_steps * 1e-3) / 1e9, 1)
             kernels[name] = k
         roofline = None
         if kernels:
@@ -230,6 +239,8 @@ def main():
             "unique_pairs": unique_pairs,
             "emitted_pairs": emitted,
             "recall_at_10": recall,
+            "kernel_timing": ("HIP events around every kernel of %d of the %d timed steps (every %d%s)"
+                              % (prof_steps, args.steps, every, "th" if every > 1 else "st")) if prof_steps else None,
             "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                         for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])},
             "roofline": roofline,

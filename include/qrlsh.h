@@ -248,9 +248,13 @@ int qrlsh_synth_fill(uint64_t seed, int64_t q0, int64_t nq_local, int64_t nq_tot
  * When enabled, every kernel launch of the library is bracketed by two HIP events recorded on
  * the launch stream.  qrlsh_prof_report waits for them and writes one "label count total_ms"
  * line per kernel label into buf_host; returns the number of labels.  enable(on) also clears
- * what was recorded so far.  bench.py uses this for the live roofline figures.
+ * what was recorded so far; pause(1) / pause(0) stops / resumes the bracketing and keeps the
+ * records (the events serialise back-to-back launches -- about 3 us per event, 10 % of a
+ * config-2 step -- so bench.py brackets every Nth step of its timed region, not all of them).
+ * bench.py uses this for the live roofline figures.
  */
 int qrlsh_prof_enable(int on);
+int qrlsh_prof_pause(int paused);
 int qrlsh_prof_report(char *buf_host, size_t buflen);
 
 #ifdef __cplusplus

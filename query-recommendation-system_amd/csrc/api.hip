@@ -71,6 +71,14 @@ QRLSH_EXPORT int qrlsh_prof_enable(int on) {
   return QRLSH_OK;
 }
 
+// stop (1) / resume (0) bracketing without discarding what has been recorded: lets a caller
+// sample some iterations of a timed loop instead of slowing all of them down
+QRLSH_EXPORT int qrlsh_prof_pause(int paused) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_on = paused == 0;
+  return QRLSH_OK;
+}
+
 // Writes "label count total_ms\n" lines (one per label) into buf; returns the number of
 // labels, or a negative error.  Blocks until the recorded events have completed.
 QRLSH_EXPORT int qrlsh_prof_report(char *buf, size_t buflen) {

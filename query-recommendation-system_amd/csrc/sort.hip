@@ -352,6 +352,120 @@ __global__ __launch_bounds__(SORT_THREADS, 4) void sort_scatter_staged_kernel(co
   }
 }
 
+// The same staging for the key + id partition passes of the fast bucket path (digit = part_digit,
+// SPREAD).  Ids are < 2^24 there (the host checks nq), so the digit rides in the top byte of the
+// staged id and is not recomputed (mix64 again) when the tile is written out.
+template <bool IOTA>
+__global__ __launch_bounds__(SORT_THREADS, 3) void part_scatter_staged_kernel(
+    const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint64_t *__restrict__ keys_out,
+    uint32_t *__restrict__ vals_out, int64_t n, int ntiles, int shift, const uint32_t *__restrict__ goff,
+    const uint32_t *__restrict__ rtot, uint64_t ek, uint32_t dmask) {
+  __shared__ uint32_t cnt[SORT_THREADS / WAVE][RADIX];
+  __shared__ uint32_t dsum[SORT_THREADS / WAVE];
+  __shared__ uint32_t lsum[SORT_THREADS / WAVE];
+  __shared__ uint32_t gdelta[RADIX];
+  __shared__ uint64_t skey[SORT_TILE];
+  __shared__ uint32_t sval[SORT_TILE];
+  const int tile = xcd_tile(blockIdx.x, ntiles), batch = blockIdx.y;
+  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < SORT_THREADS / WAVE; ++i) cnt[i][threadIdx.x] = 0;
+  __syncthreads();
+  const size_t boff = (size_t)batch * n;
+  const int64_t tbase = (int64_t)tile * SORT_TILE;
+  const int64_t wbase = tbase + (int64_t)w * (WAVE * SORT_IPT);
+  uint64_t key[SORT_IPT];
+  uint32_t val[SORT_IPT];
+  uint32_t dr[SORT_IPT];
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int k = 0; k < SORT_IPT; ++k) {
+    const int64_t idx = wbase + (int64_t)k * WAVE + lane;
+    const bool valid = idx < n;
+    key[k] = valid ? keys_in[boff + idx] : 0;
+    val[k] = IOTA ? (uint32_t)idx : (valid ? vals_in[boff + idx] : 0);
+  }
+#pragma unroll
+  for (int k = 0; k < SORT_IPT; ++k) {
+    const int64_t idx = wbase + (int64_t)k * WAVE + lane;
+    const bool valid = idx < n;
+    const uint32_t d = part_digit<true>(key[k], (int64_t)val[k], shift, ek, dmask);
+    uint64_t m = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+      const bool one = (d >> bit) & 1u;
+      const uint64_t bal = __ballot(one);
+      m &= one ? bal : ~bal;
+    }
+    const uint32_t below = (uint32_t)__popcll(m & lt_mask);
+    uint32_t prev = 0;
+    if (valid) {
+      prev = cnt[w][d];
+      if (below == 0) cnt[w][d] = prev + (uint32_t)__popcll(m);
+    }
+    dr[k] = (d << 16) | (prev + below);
+  }
+  __syncthreads();
+  {
+    const int d = threadIdx.x;
+    const uint32_t tot = rtot[(size_t)batch * RADIX + d];
+    uint32_t tc = 0;
+#pragma unroll
+    for (int i = 0; i < SORT_THREADS / WAVE; ++i) tc += cnt[i][d];
+    uint32_t inc = tot, linc = tc;
+#pragma unroll
+    for (int k = 1; k < WAVE; k <<= 1) {
+      const uint32_t o = __shfl_up(inc, k, WAVE), lo = __shfl_up(linc, k, WAVE);
+      if (lane >= k) {
+        inc += o;
+        linc += lo;
+      }
+    }
+    if (lane == WAVE - 1) {
+      dsum[w] = inc;
+      lsum[w] = linc;
+    }
+    __syncthreads();
+    uint32_t dbase = inc - tot, lstart = linc - tc;
+#pragma unroll
+    for (int k = 0; k < SORT_THREADS / WAVE; ++k)
+      if (k < w) {
+        dbase += dsum[k];
+        lstart += lsum[k];
+      }
+    gdelta[d] = dbase + goff[((size_t)batch * RADIX + d) * ntiles + tile] - lstart;
+    uint32_t run = lstart;
+#pragma unroll
+    for (int i = 0; i < SORT_THREADS / WAVE; ++i) {
+      const uint32_t c = cnt[i][d];
+      cnt[i][d] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < SORT_IPT; ++k) {
+    const int64_t idx = wbase + (int64_t)k * WAVE + lane;
+    if (idx < n) {
+      const uint32_t d = dr[k] >> 16, lp = cnt[w][d] + (dr[k] & 0xFFFFu);
+      skey[lp] = key[k];
+      sval[lp] = val[k] | d << 24;
+    }
+  }
+  __syncthreads();
+  const int ntile = (int)min((int64_t)SORT_TILE, n - tbase);
+#pragma unroll
+  for (int k = 0; k < SORT_IPT; ++k) {
+    const int p = k * SORT_THREADS + threadIdx.x;
+    if (p < ntile) {
+      const uint32_t vv = sval[p];
+      const size_t dst = boff + gdelta[vv >> 24] + (uint32_t)p;
+      keys_out[dst] = skey[p];
+      vals_out[dst] = vv & 0xFFFFFFu;
+    }
+  }
+}
+
 QRLSH_EXPORT size_t qrlsh_sort_workspace_bytes(int64_t n, int32_t nbatch) {
   if (n <= 0 || nbatch <= 0) return 16;
   const int64_t ntiles = ceil_div64(n, SORT_TILE);
@@ -700,26 +814,40 @@ QRLSH_EXPORT int qrlsh_bucket_pairs_count(const uint64_t *keys, uint64_t *part_k
   const dim3 grid(ntiles, b), block(SORT_THREADS);
   const uint64_t ek = qr_empty_key(r);
   const uint32_t *no_vals = nullptr;
+  const bool staged = nq <= (1ll << 24);  // ids fit 24 bits: the LDS-staged scatter carries the digit beside them
   if (T == 8) {
     QR_LAUNCH("sort_hist", (sort_hist_kernel<SM_MIX, true>), grid, block, 0, st, keys, nq, ntiles, 56, w.ghist, ek, 0,
               (uint32_t)RADIX - 1u, no_vals);
     QR_LAUNCH("sort_rowscan", sort_rowscan_kernel, dim3(RADIX, b), dim3(256), 0, st, w.ghist, ntiles, w.rtot);
-    QR_LAUNCH("sort_scatter_kv", (sort_scatter_kernel<SM_MIX, true, true, true>), grid, block, 0, st, keys, no_vals,
-              part_keys, part_ids, nq, ntiles, 56, w.ghist, w.rtot, ek, 0, (uint32_t)RADIX - 1u);
+    if (staged)
+      QR_LAUNCH("sort_scatter_kv", (part_scatter_staged_kernel<true>), grid, block, 0, st, keys, no_vals, part_keys,
+                part_ids, nq, ntiles, 56, w.ghist, w.rtot, ek, (uint32_t)RADIX - 1u);
+    else
+      QR_LAUNCH("sort_scatter_kv", (sort_scatter_kernel<SM_MIX, true, true, true>), grid, block, 0, st, keys, no_vals,
+                part_keys, part_ids, nq, ntiles, 56, w.ghist, w.rtot, ek, 0, (uint32_t)RADIX - 1u);
   } else {
     // LSD over the T-bit part number: low T-8 bits first, then the top 8
     const uint32_t lowmask = (1u << (T - 8)) - 1u;
     QR_LAUNCH("sort_hist", (sort_hist_kernel<SM_MIX, true>), grid, block, 0, st, keys, nq, ntiles, 64 - T, w.ghist, ek, 0,
               lowmask, no_vals);
     QR_LAUNCH("sort_rowscan", sort_rowscan_kernel, dim3(RADIX, b), dim3(256), 0, st, w.ghist, ntiles, w.rtot);
-    QR_LAUNCH("sort_scatter_kv", (sort_scatter_kernel<SM_MIX, true, true, true>), grid, block, 0, st, keys, no_vals,
-              tmp_keys, tmp_ids, nq, ntiles, 64 - T, w.ghist, w.rtot, ek, 0, lowmask);
+    if (staged)
+      QR_LAUNCH("sort_scatter_kv", (part_scatter_staged_kernel<true>), grid, block, 0, st, keys, no_vals, tmp_keys,
+                tmp_ids, nq, ntiles, 64 - T, w.ghist, w.rtot, ek, lowmask);
+    else
+      QR_LAUNCH("sort_scatter_kv", (sort_scatter_kernel<SM_MIX, true, true, true>), grid, block, 0, st, keys, no_vals,
+                tmp_keys, tmp_ids, nq, ntiles, 64 - T, w.ghist, w.rtot, ek, 0, lowmask);
     QR_LAUNCH("sort_hist", (sort_hist_kernel<SM_MIX, true>), grid, block, 0, st, (const uint64_t *)tmp_keys, nq, ntiles,
               56, w.ghist, ek, 0, (uint32_t)RADIX - 1u, (const uint32_t *)tmp_ids);
     QR_LAUNCH("sort_rowscan", sort_rowscan_kernel, dim3(RADIX, b), dim3(256), 0, st, w.ghist, ntiles, w.rtot);
-    QR_LAUNCH("sort_scatter_kv", (sort_scatter_kernel<SM_MIX, true, false, true>), grid, block, 0, st,
-              (const uint64_t *)tmp_keys, (const uint32_t *)tmp_ids, part_keys, part_ids, nq, ntiles, 56, w.ghist,
-              w.rtot, ek, 0, (uint32_t)RADIX - 1u);
+    if (staged)
+      QR_LAUNCH("sort_scatter_kv", (part_scatter_staged_kernel<false>), grid, block, 0, st, (const uint64_t *)tmp_keys,
+                (const uint32_t *)tmp_ids, part_keys, part_ids, nq, ntiles, 56, w.ghist, w.rtot, ek,
+                (uint32_t)RADIX - 1u);
+    else
+      QR_LAUNCH("sort_scatter_kv", (sort_scatter_kernel<SM_MIX, true, false, true>), grid, block, 0, st,
+                (const uint64_t *)tmp_keys, (const uint32_t *)tmp_ids, part_keys, part_ids, nq, ntiles, 56, w.ghist,
+                w.rtot, ek, 0, (uint32_t)RADIX - 1u);
   }
   QR_LAUNCH("bucket_bounds", bucket_bounds_kernel, dim3((nparts + 1 + 255) / 256, b), dim3(256), 0, st,
             (const uint64_t *)part_keys, (const uint32_t *)part_ids, nq, T, ek, w.starts);

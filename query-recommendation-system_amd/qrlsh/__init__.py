@@ -19,6 +19,8 @@ from .ops import (  # noqa: F401
     emit_pairs_fast,
     emit_pairs_any,
     unique_sorted,
+    row_unique,
+    unique_pairs,
     candidate_pairs,
     score_pairs,
     topk_edges,

@@ -65,6 +65,7 @@ SIGNATURES = {
     "qrlsh_predict": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i32, ctypes.c_double, ctypes.c_double,
                                      ctypes.c_double, _vp, _vp]),
     "qrlsh_prof_enable": (ctypes.c_int, [ctypes.c_int]),
+    "qrlsh_prof_pause": (ctypes.c_int, [ctypes.c_int]),
     "qrlsh_prof_report": (ctypes.c_int, [ctypes.c_char_p, _sz]),
     "qrlsh_synth_sizes": (ctypes.c_int, [_u64, _i64, _i64, _i64, _i32, _u32, _vp, _i32, _u32, _vp, _vp]),
     "qrlsh_synth_fill": (ctypes.c_int, [_u64, _i64, _i64, _i64, _i32, _u32, _vp, _i32, _u32, _vp, _vp, _vp]),
@@ -110,6 +111,11 @@ def check(rc):
 
 def prof_enable(on=True):
     check(load().qrlsh_prof_enable(1 if on else 0))
+
+
+def prof_pause(paused=True):
+    """stop / resume the event bracketing without clearing the records"""
+    check(load().qrlsh_prof_pause(1 if paused else 0))
 
 
 def prof_report():

@@ -43,8 +43,12 @@ class HipBackend:
     def sort_unique(self, words, bit_ranges):
         # bit_ranges = [(0, ib), (32, 32 + ib)]: pair words i << 32 | j
         ib = bit_ranges[0][1]
-        words, _ = ops.sort_u64(words, None, 0, 2 * ib, fold=ib)
-        return ops.unique_sorted(words)
+        grouped, _ = ops.sort_u64(words, None, 32, 32 + ib)      # by i only; rows are finished in LDS
+        pairs = ops.row_unique(grouped)
+        if pairs is None:                                        # a row too long for the LDS image
+            words, _ = ops.sort_u64(grouped, None, 0, 2 * ib, fold=ib)
+            pairs = ops.unique_sorted(words)
+        return pairs
 
     def sort_words(self, words, lo, hi):
         return ops.sort_u64(words, None, lo, hi)[0]
