@@ -631,10 +631,11 @@ __global__ __launch_bounds__(FIN_THREADS, 8) void bucket_finish_kernel(const uin
                                                                        uint64_t *__restrict__ blk,
                                                                        uint32_t *__restrict__ overflow,
                                                                        uint64_t *__restrict__ out) {
-  __shared__ uint64_t sk[FIN_CAP];
+  // the key image is one raw block: once the walks are over it is re-cut into two uint32 arrays
+  __shared__ __attribute__((aligned(16))) uint64_t sk[FIN_CAP];
   __shared__ uint32_t head[FIN_HT];
   __shared__ uint16_t nxt[FIN_CAP];
-  __shared__ uint64_t wsum[FIN_THREADS / WAVE];
+  __shared__ uint32_t wsum[FIN_THREADS / WAVE];
   const int part = blockIdx.x, band = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid >> 6;
   const uint32_t start = starts[(size_t)band * (nparts + 1) + part];
@@ -677,79 +678,108 @@ __global__ __launch_bounds__(FIN_THREADS, 8) void bucket_finish_kernel(const uin
   }
   __syncthreads();
 
-  uint32_t c[FIN_IPT];
-  uint32_t m12[FIN_IPT];  // FILL: positions of the first two matches, u1 | u2 << 16
-  uint64_t mine = 0;
+  // c = number of EARLIER records of the part with the same full key = the record's rank inside
+  // its bucket; hd = position of the bucket's earliest record (FILL only)
+  uint32_t ch[FIN_IPT];  // c << 16 | hd (both < FIN_CAP <= 65535)
+  uint32_t live = 0;     // bit j: record j holds a real (non-empty) key
+  uint32_t mine = 0;
 #pragma unroll
   for (int j = 0; j < FIN_IPT; ++j) {
     const uint32_t i = tid + j * FIN_THREADS;
-    uint32_t cnt = 0, mm = 0;
+    uint32_t cnt = 0, h = i;
     if (kreg[j] != ek) {
+      live |= 1u << j;
       for (uint32_t u = head[slot[j]] & 0xFFFFu; u != FIN_NIL; u = nxt[u])
         if (u < i && sk[u] == kreg[j]) {
-          if (FILL && cnt < 2) mm |= u << (16 * cnt);
+          if (FILL) h = min(h, u);
           ++cnt;
         }
     }
-    c[j] = cnt;
-    m12[j] = mm;
+    ch[j] = cnt << 16 | h;
     mine += cnt;
   }
-  // block exclusive scan over 1024 threads
-  const uint64_t inc = wave_incl_scan_u64(mine);
+  // block exclusive scan over 1024 threads (a part emits < 2^32 pairs: FIN_CAP^2 / 2)
+  uint32_t inc = mine;
+#pragma unroll
+  for (int d = 1; d < WAVE; d <<= 1) {
+    const uint32_t o = __shfl_up(inc, d, WAVE);
+    if (lane >= d) inc += o;
+  }
   if (lane == WAVE - 1) wsum[w] = inc;
-  __syncthreads();
-  uint64_t base = 0, tot = 0;
+  __syncthreads();  // also: every walk is over, the key image is dead
+  uint32_t base = 0, tot = 0;
 #pragma unroll
   for (int i = 0; i < FIN_THREADS / WAVE; ++i) {
-    const uint64_t x = wsum[i];
+    const uint32_t x = wsum[i];
     if (i < w) base += x;
     tot += x;
   }
   if (!FILL) {
-    if (tid == 0) blk[bslot] = tot;
+    if (tid == 0) blk[bslot] = (uint64_t)tot;
     return;
   }
-  // Emission without a global load inside a chain walk.  The ids came in with the keys
-  // (registers); once every walk is over the key image is dead and its space holds the ids of
-  // all records, so a match position u turns into a query id with one LDS read.  Matches beyond
-  // the second of a record (buckets of 4+) are rare: a second walk, done while the keys are
-  // still in LDS, writes them straight out with a global id gather.
-  const uint64_t pos0 = blk[bslot] + base + inc - mine;
-  {
-    uint64_t pos = pos0;
-#pragma unroll
-    for (int j = 0; j < FIN_IPT; ++j) {
-      if (c[j] > 2) {
-        const uint32_t i = tid + j * FIN_THREADS;
-        uint32_t seen = 0;
-        for (uint32_t u = head[slot[j]] & 0xFFFFu; u != FIN_NIL; u = nxt[u])
-          if (u < i && sk[u] == kreg[j]) {
-            if (seen >= 2) out[pos + seen] = ((uint64_t)id[u] << 32) | ireg[j];
-            ++seen;
-          }
-      }
-      pos += c[j];
-    }
-  }
-  __syncthreads();  // all walks done: sk is free
-  uint32_t *si = reinterpret_cast<uint32_t *>(sk);
+  // Emission without chain walks or global gathers: the ids of every bucket are laid out next to each
+  // other in LDS, in rank (= position = id) order, so the partners of a record of rank r are the r
+  // ids that precede it in its bucket's run.
+  //   bsz[h]  : size of the bucket whose earliest record is h  ->  (scan)  start of its run
+  //   grp[..] : ids, bucket by bucket
+  uint32_t *bsz = reinterpret_cast<uint32_t *>(sk);
+  uint32_t *grp = bsz + FIN_CAP;
+  __shared__ uint32_t wsum32[FIN_THREADS / WAVE];
 #pragma unroll
   for (int j = 0; j < FIN_IPT; ++j) {
     const uint32_t i = tid + j * FIN_THREADS;
-    if (i < m) si[i] = ireg[j];
+    if (i < m) bsz[i] = 0;
   }
   __syncthreads();
+#pragma unroll
+  for (int j = 0; j < FIN_IPT; ++j)
+    if (live >> j & 1u) atomicMax(&bsz[ch[j] & 0xFFFFu], (ch[j] >> 16) + 1u);
+  __syncthreads();
   {
-    uint64_t pos = pos0;
+    // exclusive scan of bsz over the part, blocked layout (FIN_IPT consecutive positions per thread)
+    const uint32_t b0 = tid * FIN_IPT;
+    uint32_t v[FIN_IPT], sum = 0;
+#pragma unroll
+    for (int k = 0; k < FIN_IPT; ++k) {
+      v[k] = b0 + k < m ? bsz[b0 + k] : 0u;
+      sum += v[k];
+    }
+    uint32_t sinc = sum;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+      const uint32_t o = __shfl_up(sinc, d, WAVE);
+      if (lane >= d) sinc += o;
+    }
+    if (lane == WAVE - 1) wsum32[w] = sinc;
+    __syncthreads();
+    uint32_t run = sinc - sum;
+#pragma unroll
+    for (int i = 0; i < FIN_THREADS / WAVE; ++i)
+      if (i < w) run += wsum32[i];
+#pragma unroll
+    for (int k = 0; k < FIN_IPT; ++k) {
+      if (b0 + k < m) bsz[b0 + k] = run;
+      run += v[k];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < FIN_IPT; ++j)
+    if (live >> j & 1u) grp[bsz[ch[j] & 0xFFFFu] + (ch[j] >> 16)] = ireg[j];
+  __syncthreads();
+  {
+    uint64_t *dst = out + blk[bslot];
+    uint32_t pos = base + inc - mine;
 #pragma unroll
     for (int j = 0; j < FIN_IPT; ++j) {
-      if (c[j] != 0) {
+      const uint32_t cj = ch[j] >> 16;
+      if (cj != 0) {
         const uint64_t lo = ireg[j];
-        out[pos] = ((uint64_t)si[m12[j] & 0xFFFFu] << 32) | lo;
-        if (c[j] > 1) out[pos + 1] = ((uint64_t)si[m12[j] >> 16] << 32) | lo;
+        const uint32_t *run = grp + bsz[ch[j] & 0xFFFFu];
+        for (uint32_t t = 0; t < cj; ++t) dst[pos + t] = ((uint64_t)run[t] << 32) | lo;
       }
-      pos += c[j];
+      pos += cj;
     }
   }
 }
