@@ -585,19 +585,7 @@ QRLSH_EXPORT int qrlsh_owner_bounds(const uint64_t *words, int64_t n, int32_t bi
 // ==========================================================================================
 constexpr int FIN_THREADS = 1024;
 constexpr int FIN_CAP = 6144;   // records per part that fit the LDS image
-constexpr int FIN_HT = 4096;    // hash-table heads
 constexpr int FIN_IPT = FIN_CAP / FIN_THREADS;
-constexpr uint32_t FIN_NIL = 0xFFFFu;
-
-// cheap 32-bit slot hash for the LDS table (quality only affects chain length, never results)
-__device__ static inline uint32_t fin_slot(uint64_t key) {
-  uint32_t h = (uint32_t)key * 0x9E3779B1u;
-  h ^= h >> 15;
-  h += (uint32_t)(key >> 32) * 0x85EBCA77u;
-  h ^= h >> 13;
-  h *= 0xC2B2AE3Du;
-  return h >> (32 - 12);  // FIN_HT = 4096
-}
 
 // starts[band][f] = first position of band `band` whose T-bit part number is >= f (f = 0 .. 2^T)
 __global__ __launch_bounds__(256) void bucket_bounds_kernel(const uint64_t *__restrict__ keys,
@@ -619,10 +607,26 @@ __global__ __launch_bounds__(256) void bucket_bounds_kernel(const uint64_t *__re
   starts[(size_t)band * (nparts + 1) + f] = (uint32_t)lo;
 }
 
-// The partition passes are stable and ids enter in ascending order (IOTA), so inside a part
-// "smaller query id" == "earlier position": the finish never needs the ids to decide, only to
-// write a pair.  LDS image: keys 48 KB + heads 16 KB + links 12 KB = 76 KB -> two workgroups per
-// CU (which also needs <= 64 VGPRs: __launch_bounds__(1024, 8)).
+// Finish of one (part, band): an open-addressing hash table in LDS keyed by the FULL 64-bit key
+// (ds_cmpst_b64 claims a slot or finds the key present; the empty-band key, which never enters a
+// bucket, doubles as the "free slot" marker).  A record's arrival number o in its slot's counter
+// says how many records of its bucket came before it, so
+//     pairs of the part = sum of o          (count kernel: that is all it needs)
+// and, for the fill, the ids of every bucket are laid out next to each other in LDS (run start =
+// exclusive scan of the slot counters, place = o) and a record pairs with the o ids in front of
+// it in its run, ordered (smaller id, larger id).  No chains, no walks, no key re-compares.
+// LDS: table 48 KB + counters 24 KB = 72 KB -> two 1024-thread workgroups per CU (which also
+// needs <= 64 VGPRs: __launch_bounds__(1024, 8)).  Arrival order varies from run to run, so the
+// pairs of a part come out in varying order -- as a set they are exact, and the next step sorts.
+__device__ static inline uint32_t fin_home(uint64_t key) {
+  uint32_t h = (uint32_t)key * 0x9E3779B1u;
+  h ^= h >> 15;
+  h += (uint32_t)(key >> 32) * 0x85EBCA77u;
+  h ^= h >> 13;
+  h *= 0xC2B2AE3Du;
+  return __umulhi(h, (uint32_t)FIN_CAP);
+}
+
 template <bool FILL>
 __global__ __launch_bounds__(FIN_THREADS, 8) void bucket_finish_kernel(const uint64_t *__restrict__ keys,
                                                                        const uint32_t *__restrict__ ids, int64_t nq,
@@ -631,10 +635,8 @@ __global__ __launch_bounds__(FIN_THREADS, 8) void bucket_finish_kernel(const uin
                                                                        uint64_t *__restrict__ blk,
                                                                        uint32_t *__restrict__ overflow,
                                                                        uint64_t *__restrict__ out) {
-  // the key image is one raw block: once the walks are over it is re-cut into two uint32 arrays
-  __shared__ __attribute__((aligned(16))) uint64_t sk[FIN_CAP];
-  __shared__ uint32_t head[FIN_HT];
-  __shared__ uint16_t nxt[FIN_CAP];
+  __shared__ __attribute__((aligned(16))) unsigned long long tab[FIN_CAP];
+  __shared__ uint32_t cnt[FIN_CAP];
   __shared__ uint32_t wsum[FIN_THREADS / WAVE];
   const int part = blockIdx.x, band = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid >> 6;
@@ -652,7 +654,6 @@ __global__ __launch_bounds__(FIN_THREADS, 8) void bucket_finish_kernel(const uin
     if (!FILL && tid == 0) blk[bslot] = 0;
     return;
   }
-  for (int i = tid; i < FIN_HT; i += FIN_THREADS) head[i] = 0xFFFFFFFFu;
   const uint64_t *k = keys + (size_t)band * nq + start;
   const uint32_t *id = ids + (size_t)band * nq + start;
   uint64_t kreg[FIN_IPT];
@@ -666,37 +667,26 @@ __global__ __launch_bounds__(FIN_THREADS, 8) void bucket_finish_kernel(const uin
 #pragma unroll
   for (int j = 0; j < FIN_IPT; ++j) {
     const uint32_t i = tid + j * FIN_THREADS;
-    if (i < m) sk[i] = kreg[j];
+    tab[i] = ek;
+    cnt[i] = 0;
   }
   __syncthreads();
-  uint32_t slot[FIN_IPT];
-#pragma unroll
-  for (int j = 0; j < FIN_IPT; ++j) {
-    const uint32_t i = tid + j * FIN_THREADS;
-    slot[j] = fin_slot(kreg[j]);
-    if (kreg[j] != ek) nxt[i] = (uint16_t)atomicExch(&head[slot[j]], i);
-  }
-  __syncthreads();
-
-  // c = number of EARLIER records of the part with the same full key = the record's rank inside
-  // its bucket; hd = position of the bucket's earliest record (FILL only)
-  uint32_t ch[FIN_IPT];  // c << 16 | hd (both < FIN_CAP <= 65535)
-  uint32_t live = 0;     // bit j: record j holds a real (non-empty) key
+  uint32_t so[FIN_IPT];  // arrival number << 16 | slot (both < FIN_CAP <= 65535); 0xFFFFFFFF = empty band
   uint32_t mine = 0;
 #pragma unroll
   for (int j = 0; j < FIN_IPT; ++j) {
-    const uint32_t i = tid + j * FIN_THREADS;
-    uint32_t cnt = 0, h = i;
+    so[j] = 0xFFFFFFFFu;
     if (kreg[j] != ek) {
-      live |= 1u << j;
-      for (uint32_t u = head[slot[j]] & 0xFFFFu; u != FIN_NIL; u = nxt[u])
-        if (u < i && sk[u] == kreg[j]) {
-          if (FILL) h = min(h, u);
-          ++cnt;
-        }
+      uint32_t slot = fin_home(kreg[j]);
+      for (;;) {  // the table has FIN_CAP slots for at most FIN_CAP records: a free slot always turns up
+        const unsigned long long old = atomicCAS(&tab[slot], (unsigned long long)ek, (unsigned long long)kreg[j]);
+        if (old == ek || old == kreg[j]) break;
+        slot = slot + 1 == (uint32_t)FIN_CAP ? 0u : slot + 1;
+      }
+      const uint32_t o = atomicAdd(&cnt[slot], 1u);
+      so[j] = o << 16 | slot;
+      mine += o;
     }
-    ch[j] = cnt << 16 | h;
-    mine += cnt;
   }
   // block exclusive scan over 1024 threads (a part emits < 2^32 pairs: FIN_CAP^2 / 2)
   uint32_t inc = mine;
@@ -706,7 +696,7 @@ __global__ __launch_bounds__(FIN_THREADS, 8) void bucket_finish_kernel(const uin
     if (lane >= d) inc += o;
   }
   if (lane == WAVE - 1) wsum[w] = inc;
-  __syncthreads();  // also: every walk is over, the key image is dead
+  __syncthreads();  // also: every insert is over
   uint32_t base = 0, tot = 0;
 #pragma unroll
   for (int i = 0; i < FIN_THREADS / WAVE; ++i) {
@@ -718,32 +708,15 @@ __global__ __launch_bounds__(FIN_THREADS, 8) void bucket_finish_kernel(const uin
     if (tid == 0) blk[bslot] = (uint64_t)tot;
     return;
   }
-  // Emission without chain walks or global gathers: the ids of every bucket are laid out next to each
-  // other in LDS, in rank (= position = id) order, so the partners of a record of rank r are the r
-  // ids that precede it in its bucket's run.
-  //   bsz[h]  : size of the bucket whose earliest record is h  ->  (scan)  start of its run
-  //   grp[..] : ids, bucket by bucket
-  uint32_t *bsz = reinterpret_cast<uint32_t *>(sk);
-  uint32_t *grp = bsz + FIN_CAP;
-  __shared__ uint32_t wsum32[FIN_THREADS / WAVE];
-#pragma unroll
-  for (int j = 0; j < FIN_IPT; ++j) {
-    const uint32_t i = tid + j * FIN_THREADS;
-    if (i < m) bsz[i] = 0;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < FIN_IPT; ++j)
-    if (live >> j & 1u) atomicMax(&bsz[ch[j] & 0xFFFFu], (ch[j] >> 16) + 1u);
-  __syncthreads();
+  const uint32_t pos0 = base + inc - mine;
   {
-    // exclusive scan of bsz over the part, blocked layout (FIN_IPT consecutive positions per thread)
+    // run starts: exclusive scan of the slot counters, blocked layout (FIN_IPT consecutive slots per thread)
     const uint32_t b0 = tid * FIN_IPT;
     uint32_t v[FIN_IPT], sum = 0;
 #pragma unroll
-    for (int k = 0; k < FIN_IPT; ++k) {
-      v[k] = b0 + k < m ? bsz[b0 + k] : 0u;
-      sum += v[k];
+    for (int q = 0; q < FIN_IPT; ++q) {
+      v[q] = cnt[b0 + q];
+      sum += v[q];
     }
     uint32_t sinc = sum;
 #pragma unroll
@@ -751,35 +724,39 @@ __global__ __launch_bounds__(FIN_THREADS, 8) void bucket_finish_kernel(const uin
       const uint32_t o = __shfl_up(sinc, d, WAVE);
       if (lane >= d) sinc += o;
     }
-    if (lane == WAVE - 1) wsum32[w] = sinc;
+    __syncthreads();  // wsum is read by everyone above
+    if (lane == WAVE - 1) wsum[w] = sinc;
     __syncthreads();
     uint32_t run = sinc - sum;
 #pragma unroll
     for (int i = 0; i < FIN_THREADS / WAVE; ++i)
-      if (i < w) run += wsum32[i];
+      if (i < w) run += wsum[i];
 #pragma unroll
-    for (int k = 0; k < FIN_IPT; ++k) {
-      if (b0 + k < m) bsz[b0 + k] = run;
-      run += v[k];
+    for (int q = 0; q < FIN_IPT; ++q) {
+      cnt[b0 + q] = run;
+      run += v[q];
     }
   }
   __syncthreads();
+  uint32_t *grp = reinterpret_cast<uint32_t *>(tab);  // the table is dead: ids, bucket by bucket
 #pragma unroll
   for (int j = 0; j < FIN_IPT; ++j)
-    if (live >> j & 1u) grp[bsz[ch[j] & 0xFFFFu] + (ch[j] >> 16)] = ireg[j];
+    if (so[j] != 0xFFFFFFFFu) grp[cnt[so[j] & 0xFFFFu] + (so[j] >> 16)] = ireg[j];
   __syncthreads();
   {
     uint64_t *dst = out + blk[bslot];
-    uint32_t pos = base + inc - mine;
+    uint32_t pos = pos0;
 #pragma unroll
     for (int j = 0; j < FIN_IPT; ++j) {
-      const uint32_t cj = ch[j] >> 16;
-      if (cj != 0) {
-        const uint64_t lo = ireg[j];
-        const uint32_t *run = grp + bsz[ch[j] & 0xFFFFu];
-        for (uint32_t t = 0; t < cj; ++t) dst[pos + t] = ((uint64_t)run[t] << 32) | lo;
+      if (so[j] != 0xFFFFFFFFu) {
+        const uint32_t o = so[j] >> 16, me = ireg[j];
+        const uint32_t *run = grp + cnt[so[j] & 0xFFFFu];
+        for (uint32_t t = 0; t < o; ++t) {
+          const uint32_t other = run[t];
+          dst[pos + t] = (uint64_t)min(me, other) << 32 | max(me, other);
+        }
+        pos += o;
       }
-      pos += cj;
     }
   }
 }
