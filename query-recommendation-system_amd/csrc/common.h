@@ -119,7 +119,17 @@ static __global__ __launch_bounds__(1024) void scan_u64_kernel(uint64_t *__restr
   const int64_t per = (m + 1023) / 1024;
   const int64_t lo = min((int64_t)t * per, m), hi = min(lo + per, m);
   uint64_t s = 0;
-  for (int64_t i = lo; i < hi; ++i) s += a[i];
+  constexpr int SCAN_REG = 16;  // up to 16 K elements: every load is issued before the first add
+  uint64_t held[SCAN_REG];
+  const bool small = per <= SCAN_REG;
+  if (small) {
+#pragma unroll
+    for (int k = 0; k < SCAN_REG; ++k) held[k] = lo + k < hi ? a[lo + k] : 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_REG; ++k) s += held[k];
+  } else {
+    for (int64_t i = lo; i < hi; ++i) s += a[i];
+  }
   const uint64_t inc = wave_incl_scan_u64(s);
   if (lane == WAVE - 1) wsum[w] = inc;
   __syncthreads();
@@ -129,10 +139,19 @@ static __global__ __launch_bounds__(1024) void scan_u64_kernel(uint64_t *__restr
     tot += wsum[i];
   }
   uint64_t run = base + inc - s;
-  for (int64_t i = lo; i < hi; ++i) {
-    const uint64_t v = a[i];
-    a[i] = run;
-    run += v;
+  if (small) {
+#pragma unroll
+    for (int k = 0; k < SCAN_REG; ++k)
+      if (lo + k < hi) {
+        a[lo + k] = run;
+        run += held[k];
+      }
+  } else {
+    for (int64_t i = lo; i < hi; ++i) {
+      const uint64_t v = a[i];
+      a[i] = run;
+      run += v;
+    }
   }
   if (t == 0) *total_out = tot;
 }

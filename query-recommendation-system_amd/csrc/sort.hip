@@ -124,6 +124,41 @@ __global__ __launch_bounds__(256) void sort_rowscan_kernel(uint32_t *__restrict_
   const int d = blockIdx.x, batch = blockIdx.y;
   uint32_t *row = ghist + ((size_t)batch * RADIX + d) * ntiles;
   const int t = threadIdx.x, lane = t & (WAVE - 1), w = t >> 6;
+  constexpr int ROW_REG = 32;  // rows of up to 8192 tiles (33 M keys per batch) are scanned from registers
+  const int per = (ntiles + 255) / 256;
+  if (per <= ROW_REG) {
+    // blocked layout: thread t owns `per` consecutive tiles; every load is issued before the first
+    // add, and the whole row needs one workgroup scan instead of one per 256 tiles
+    const int lo = t * per;
+    uint32_t held[ROW_REG], s = 0;
+#pragma unroll
+    for (int k = 0; k < ROW_REG; ++k) held[k] = (k < per && lo + k < ntiles) ? row[lo + k] : 0u;
+#pragma unroll
+    for (int k = 0; k < ROW_REG; ++k) s += held[k];
+    uint32_t inc = s;
+#pragma unroll
+    for (int k = 1; k < WAVE; k <<= 1) {
+      const uint32_t o = __shfl_up(inc, k, WAVE);
+      if (lane >= k) inc += o;
+    }
+    if (lane == WAVE - 1) wsum[w] = inc;
+    __syncthreads();
+    uint32_t run = inc - s, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t x = wsum[k];
+      if (k < w) run += x;
+      tot += x;
+    }
+#pragma unroll
+    for (int k = 0; k < ROW_REG; ++k)
+      if (k < per && lo + k < ntiles) {
+        row[lo + k] = run;
+        run += held[k];
+      }
+    if (t == 0) rtot[(size_t)batch * RADIX + d] = tot;
+    return;
+  }
   uint32_t carry = 0;
   for (int base = 0; base < ntiles; base += 256) {
     const int i = base + t;
