@@ -70,6 +70,7 @@ def algorithmic_bytes_per_step(w):
         "sort_scatter_kv": (8 + 12) * rec,
         "bucket_count": 12 * rec,
         "bucket_fill": 12 * rec + 8 * em,
+        "bucket_emit": 12 * rec + 8 * em,             # one-pass form (cursor-reserved output ranges)
         # keys-only LSD passes: pair words, then directed edge keys
         "sort_scatter_k": 16 * (pair_passes * em + edge_passes * 2 * un),
         "sort_hist": 8 * (rec + pair_passes * em + edge_passes * 2 * un),

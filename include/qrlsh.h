@@ -136,6 +136,16 @@ int qrlsh_bucket_pairs_count(const uint64_t *keys, uint64_t *part_keys, uint32_t
 int qrlsh_bucket_pairs_fill(const uint64_t *part_keys, const uint32_t *part_ids, int64_t nq, int32_t b,
                             int32_t r, int32_t part_bits, void *workspace, uint64_t *pairs_out,
                             void *stream);
+/* One-pass form of the two calls above: every part reserves its output range on a device cursor, so
+ * the count pass (and its scan) disappears -- at the price of sizing pairs_out by a guess.  At most
+ * `capacity` words of pairs_out are written; total_overflow_out[0] receives the exact number of pairs
+ * whether or not they fitted (if it exceeds capacity: allocate that many and call again), [1] the same
+ * oversized-part flag as qrlsh_bucket_pairs_count.  The pairs come out in no particular order. */
+int qrlsh_bucket_pairs_emit(const uint64_t *keys, uint64_t *part_keys, uint32_t *part_ids,
+                            uint64_t *tmp_keys, uint32_t *tmp_ids, int64_t nq, int32_t b, int32_t r,
+                            int32_t part_bits, void *workspace, size_t workspace_bytes,
+                            uint64_t *pairs_out, uint64_t capacity, uint64_t *total_overflow_out,
+                            void *stream);
 
 /* unique of a sorted uint64 array (count-then-fill) */
 size_t qrlsh_compact_workspace_bytes(int64_t n);

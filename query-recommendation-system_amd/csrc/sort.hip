@@ -662,14 +662,22 @@ __device__ static inline uint32_t fin_home(uint64_t key) {
   return __umulhi(h, (uint32_t)FIN_CAP);
 }
 
-template <bool FILL>
+// MODE: FIN_COUNT leaves the part's pair count in blk; FIN_FILL writes the pairs at the offset the
+// scanned blk holds; FIN_EMIT does both in one go -- the workgroup reserves its output range with
+// one atomicAdd on a global cursor (blk[0]) and writes only if the range fits `capacity`; the cursor
+// ends up holding the exact total either way, so a caller whose guess was too small retries once.
+enum { FIN_COUNT = 0, FIN_FILL = 1, FIN_EMIT = 2 };
+template <int MODE>
 __global__ __launch_bounds__(FIN_THREADS, 8) void bucket_finish_kernel(const uint64_t *__restrict__ keys,
                                                                        const uint32_t *__restrict__ ids, int64_t nq,
                                                                        const uint32_t *__restrict__ starts,
                                                                        int nparts, uint64_t ek,
                                                                        uint64_t *__restrict__ blk,
                                                                        uint32_t *__restrict__ overflow,
-                                                                       uint64_t *__restrict__ out) {
+                                                                       uint64_t *__restrict__ out,
+                                                                       uint64_t capacity) {
+  constexpr bool FILL = MODE != FIN_COUNT;
+  __shared__ unsigned long long gbase;
   __shared__ __attribute__((aligned(16))) unsigned long long tab[FIN_CAP];
   __shared__ uint32_t cnt[FIN_CAP];
   __shared__ uint32_t wsum[FIN_THREADS / WAVE];
@@ -681,12 +689,12 @@ __global__ __launch_bounds__(FIN_THREADS, 8) void bucket_finish_kernel(const uin
   if (m > (uint32_t)FIN_CAP) {  // uniform over the workgroup
     if (tid == 0) {
       atomicOr(overflow, 1u);
-      if (!FILL) blk[bslot] = 0;
+      if (MODE == FIN_COUNT) blk[bslot] = 0;
     }
     return;
   }
   if (m == 0) {
-    if (!FILL && tid == 0) blk[bslot] = 0;
+    if (MODE == FIN_COUNT && tid == 0) blk[bslot] = 0;
     return;
   }
   const uint64_t *k = keys + (size_t)band * nq + start;
@@ -739,9 +747,15 @@ __global__ __launch_bounds__(FIN_THREADS, 8) void bucket_finish_kernel(const uin
     if (i < w) base += x;
     tot += x;
   }
-  if (!FILL) {
+  if (MODE == FIN_COUNT) {
     if (tid == 0) blk[bslot] = (uint64_t)tot;
     return;
+  }
+  if (MODE == FIN_EMIT) {
+    if (tot == 0) return;  // uniform
+    if (tid == 0)
+      gbase = __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(blk), (unsigned long long)tot,
+                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   const uint32_t pos0 = base + inc - mine;
   {
@@ -779,7 +793,9 @@ __global__ __launch_bounds__(FIN_THREADS, 8) void bucket_finish_kernel(const uin
     if (so[j] != 0xFFFFFFFFu) grp[cnt[so[j] & 0xFFFFu] + (so[j] >> 16)] = ireg[j];
   __syncthreads();
   {
-    uint64_t *dst = out + blk[bslot];
+    const uint64_t obase = MODE == FIN_EMIT ? (uint64_t)gbase : blk[bslot];
+    if (MODE == FIN_EMIT && obase + tot > capacity) return;  // uniform: counted, not written
+    uint64_t *dst = out + obase;
     uint32_t pos = pos0;
 #pragma unroll
     for (int j = 0; j < FIN_IPT; ++j) {
@@ -828,31 +844,12 @@ QRLSH_EXPORT size_t qrlsh_bucket_workspace_bytes(int64_t nq, int32_t b, int32_t 
   return bucket_ws(nullptr, nq, b, part_bits).bytes;
 }
 
-QRLSH_EXPORT int qrlsh_bucket_pairs_count(const uint64_t *keys, uint64_t *part_keys, uint32_t *part_ids,
-                                          uint64_t *tmp_keys, uint32_t *tmp_ids, int64_t nq, int32_t b, int32_t r,
-                                          int32_t part_bits, void *workspace, size_t workspace_bytes,
-                                          uint64_t *total_overflow_out, void *stream) {
-  QR_CHECK_ARG(nq >= 0 && b > 0 && b <= 65535 && r > 0, "qrlsh_bucket_pairs_count: bad sizes nq=%lld b=%d r=%d",
-               (long long)nq, b, r);
-  QR_CHECK_ARG(part_bits >= 8 && part_bits <= 16, "qrlsh_bucket_pairs_count: part_bits=%d not in [8,16]", part_bits);
-  QR_CHECK_ARG(nq < (1ll << 32), "qrlsh_bucket_pairs_count: nq too large");
-  QR_CHECK_ARG(total_overflow_out && workspace, "qrlsh_bucket_pairs_count: null pointer");
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if (hipMemsetAsync(total_overflow_out, 0, 2 * sizeof(uint64_t), st) != hipSuccess) {
-    qrlsh_set_error("qrlsh_bucket_pairs_count: hipMemsetAsync failed");
-    return QRLSH_EHIP;
-  }
-  if (nq == 0) return QRLSH_OK;
-  QR_CHECK_ARG(keys && part_keys && part_ids, "qrlsh_bucket_pairs_count: null pointer");
-  QR_CHECK_ARG(part_bits == 8 || (tmp_keys && tmp_ids), "qrlsh_bucket_pairs_count: part_bits > 8 needs tmp buffers");
-  if (workspace_bytes < qrlsh_bucket_workspace_bytes(nq, b, part_bits)) {
-    qrlsh_set_error("qrlsh_bucket_pairs_count: workspace %zu < %zu bytes", workspace_bytes,
-                    qrlsh_bucket_workspace_bytes(nq, b, part_bits));
-    return QRLSH_EWORKSPACE;
-  }
+// partition (one or two radix passes on the T-bit part number) + part bounds
+static void bucket_partition(const uint64_t *keys, uint64_t *part_keys, uint32_t *part_ids, uint64_t *tmp_keys,
+                             uint32_t *tmp_ids, int64_t nq, int32_t b, int32_t r, int32_t part_bits, const BucketWs &w,
+                             hipStream_t st) {
   const int T = part_bits, nparts = 1 << T;
   const int ntiles = (int)ceil_div64(nq, SORT_TILE);
-  const BucketWs w = bucket_ws(workspace, nq, b, T);
   const dim3 grid(ntiles, b), block(SORT_THREADS);
   const uint64_t ek = qr_empty_key(r);
   const uint32_t *no_vals = nullptr;
@@ -893,11 +890,72 @@ QRLSH_EXPORT int qrlsh_bucket_pairs_count(const uint64_t *keys, uint64_t *part_k
   }
   QR_LAUNCH("bucket_bounds", bucket_bounds_kernel, dim3((nparts + 1 + 255) / 256, b), dim3(256), 0, st,
             (const uint64_t *)part_keys, (const uint32_t *)part_ids, nq, T, ek, w.starts);
-  QR_LAUNCH("bucket_count", (bucket_finish_kernel<false>), dim3(nparts, b), dim3(FIN_THREADS), 0, st,
+}
+
+static int bucket_check(const char *name, const uint64_t *keys, uint64_t *part_keys, uint32_t *part_ids,
+                        uint64_t *tmp_keys, uint32_t *tmp_ids, int64_t nq, int32_t b, int32_t r, int32_t part_bits,
+                        void *workspace, size_t workspace_bytes, uint64_t *total_overflow_out, hipStream_t st) {
+  QR_CHECK_ARG(nq >= 0 && b > 0 && b <= 65535 && r > 0, "%s: bad sizes nq=%lld b=%d r=%d", name, (long long)nq, b, r);
+  QR_CHECK_ARG(part_bits >= 8 && part_bits <= 16, "%s: part_bits=%d not in [8,16]", name, part_bits);
+  QR_CHECK_ARG(nq < (1ll << 32), "%s: nq too large", name);
+  QR_CHECK_ARG(total_overflow_out && workspace, "%s: null pointer", name);
+  if (hipMemsetAsync(total_overflow_out, 0, 2 * sizeof(uint64_t), st) != hipSuccess) {
+    qrlsh_set_error("%s: hipMemsetAsync failed", name);
+    return QRLSH_EHIP;
+  }
+  if (nq == 0) return QRLSH_OK;
+  QR_CHECK_ARG(keys && part_keys && part_ids, "%s: null pointer", name);
+  QR_CHECK_ARG(part_bits == 8 || (tmp_keys && tmp_ids), "%s: part_bits > 8 needs tmp buffers", name);
+  if (workspace_bytes < qrlsh_bucket_workspace_bytes(nq, b, part_bits)) {
+    qrlsh_set_error("%s: workspace %zu < %zu bytes", name, workspace_bytes,
+                    qrlsh_bucket_workspace_bytes(nq, b, part_bits));
+    return QRLSH_EWORKSPACE;
+  }
+  return QRLSH_OK;
+}
+
+QRLSH_EXPORT int qrlsh_bucket_pairs_count(const uint64_t *keys, uint64_t *part_keys, uint32_t *part_ids,
+                                          uint64_t *tmp_keys, uint32_t *tmp_ids, int64_t nq, int32_t b, int32_t r,
+                                          int32_t part_bits, void *workspace, size_t workspace_bytes,
+                                          uint64_t *total_overflow_out, void *stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int rc = bucket_check("qrlsh_bucket_pairs_count", keys, part_keys, part_ids, tmp_keys, tmp_ids, nq, b, r,
+                              part_bits, workspace, workspace_bytes, total_overflow_out, st);
+  if (rc != QRLSH_OK || nq == 0) return rc;
+  const int nparts = 1 << part_bits;
+  const uint64_t ek = qr_empty_key(r);
+  const BucketWs w = bucket_ws(workspace, nq, b, part_bits);
+  bucket_partition(keys, part_keys, part_ids, tmp_keys, tmp_ids, nq, b, r, part_bits, w, st);
+  QR_LAUNCH("bucket_count", (bucket_finish_kernel<FIN_COUNT>), dim3(nparts, b), dim3(FIN_THREADS), 0, st,
             (const uint64_t *)part_keys, (const uint32_t *)part_ids, nq, (const uint32_t *)w.starts, nparts, ek, w.blk,
-            reinterpret_cast<uint32_t *>(total_overflow_out + 1), (uint64_t *)nullptr);
+            reinterpret_cast<uint32_t *>(total_overflow_out + 1), (uint64_t *)nullptr, (uint64_t)0);
   QR_LAUNCH("scan_blocks", scan_u64_kernel, dim3(1), dim3(1024), 0, st, w.blk, (int64_t)b * nparts, total_overflow_out);
   QR_LAUNCH_CHECK("qrlsh_bucket_pairs_count");
+  return QRLSH_OK;
+}
+
+// One-pass form: partition + finish with the output range of every part reserved on a device cursor.
+// total_overflow_out[0] ends up holding the exact number of pairs whether or not they fitted
+// `capacity` words of pairs_out (nothing is written past it); [1] != 0 flags an oversized part.
+QRLSH_EXPORT int qrlsh_bucket_pairs_emit(const uint64_t *keys, uint64_t *part_keys, uint32_t *part_ids,
+                                         uint64_t *tmp_keys, uint32_t *tmp_ids, int64_t nq, int32_t b, int32_t r,
+                                         int32_t part_bits, void *workspace, size_t workspace_bytes,
+                                         uint64_t *pairs_out, uint64_t capacity, uint64_t *total_overflow_out,
+                                         void *stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int rc = bucket_check("qrlsh_bucket_pairs_emit", keys, part_keys, part_ids, tmp_keys, tmp_ids, nq, b, r,
+                              part_bits, workspace, workspace_bytes, total_overflow_out, st);
+  if (rc != QRLSH_OK || nq == 0) return rc;
+  QR_CHECK_ARG(pairs_out || capacity == 0, "qrlsh_bucket_pairs_emit: null output with capacity %llu",
+               (unsigned long long)capacity);
+  const int nparts = 1 << part_bits;
+  const BucketWs w = bucket_ws(workspace, nq, b, part_bits);
+  bucket_partition(keys, part_keys, part_ids, tmp_keys, tmp_ids, nq, b, r, part_bits, w, st);
+  QR_LAUNCH("bucket_emit", (bucket_finish_kernel<FIN_EMIT>), dim3(nparts, b), dim3(FIN_THREADS), 0, st,
+            (const uint64_t *)part_keys, (const uint32_t *)part_ids, nq, (const uint32_t *)w.starts, nparts,
+            qr_empty_key(r), total_overflow_out, reinterpret_cast<uint32_t *>(total_overflow_out + 1), pairs_out,
+            capacity);
+  QR_LAUNCH_CHECK("qrlsh_bucket_pairs_emit");
   return QRLSH_OK;
 }
 
@@ -910,9 +968,9 @@ QRLSH_EXPORT int qrlsh_bucket_pairs_fill(const uint64_t *part_keys, const uint32
   QR_CHECK_ARG(part_keys && part_ids && workspace && pairs_out, "qrlsh_bucket_pairs_fill: null pointer");
   const int nparts = 1 << part_bits;
   const BucketWs w = bucket_ws(workspace, nq, b, part_bits);
-  QR_LAUNCH("bucket_fill", (bucket_finish_kernel<true>), dim3(nparts, b), dim3(FIN_THREADS), 0,
+  QR_LAUNCH("bucket_fill", (bucket_finish_kernel<FIN_FILL>), dim3(nparts, b), dim3(FIN_THREADS), 0,
             static_cast<hipStream_t>(stream), part_keys, part_ids, nq, (const uint32_t *)w.starts, nparts,
-            qr_empty_key(r), w.blk, w.tail, pairs_out);
+            qr_empty_key(r), w.blk, w.tail, pairs_out, (uint64_t)0);
   QR_LAUNCH_CHECK("qrlsh_bucket_pairs_fill");
   return QRLSH_OK;
 }

@@ -316,9 +316,16 @@ def part_bits_for(n):
     return t
 
 
-def emit_pairs_fast(keys, r, part_bits=None):
+_EMIT_HINT = {}   # (nq, b, r) -> pairs emitted by the last call of that shape: the next call's capacity guess
+
+
+def emit_pairs_fast(keys, r, part_bits=None, one_pass=True, capacity=None):
     """emit_pairs for unsorted band-major keys through the partition + LDS-finish path.
-    Returns the pairs tensor, or None when a part overflowed the LDS image (skewed data)."""
+    Returns the pairs tensor, or None when a part overflowed the LDS image (skewed data).
+    one_pass: the parts reserve their output ranges on a device cursor (qrlsh_bucket_pairs_emit), so
+    no count pass runs; the output buffer is sized by `capacity` (default: 1.25 x what the last call
+    of this shape emitted, else 24 pairs per query) and the call is repeated once, exactly sized,
+    if that was too small.  one_pass=False is the count-then-fill form."""
     lib = _lib.load()
     _need(keys, torch.int64, "keys", 2)
     b, nq = keys.shape
@@ -332,6 +339,22 @@ def emit_pairs_fast(keys, r, part_bits=None):
     tid = torch.empty((b, nq), dtype=torch.int32, device=dev) if T > 8 else None
     ws = _ws(lib.qrlsh_bucket_workspace_bytes(nq, b, T), dev)
     tot = torch.zeros(2, dtype=torch.int64, device=dev)
+    if one_pass:
+        shape = (nq, b, r)
+        if capacity is None:
+            capacity = _EMIT_HINT[shape] * 5 // 4 + 1024 if shape in _EMIT_HINT else 24 * nq + 1024
+        while True:
+            pairs = torch.empty((capacity,), dtype=torch.int64, device=dev)
+            _lib.check(lib.qrlsh_bucket_pairs_emit(_ptr(keys), _ptr(pk), _ptr(pid), _ptr(tk), _ptr(tid), nq, b, r, T,
+                                                   _ptr(ws), ws.numel(), _ptr(pairs), capacity, _ptr(tot), _stream()))
+            n, overflow = tot.tolist()
+            if overflow:
+                return None
+            _EMIT_HINT[shape] = n
+            if n <= capacity:
+                return pairs[:n]
+            del pairs
+            capacity = n       # the cursor counted everything: the second run fits exactly
     _lib.check(lib.qrlsh_bucket_pairs_count(_ptr(keys), _ptr(pk), _ptr(pid), _ptr(tk), _ptr(tid), nq, b, r, T,
                                             _ptr(ws), ws.numel(), _ptr(tot), _stream()))
     n, overflow = tot.tolist()

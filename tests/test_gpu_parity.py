@@ -452,9 +452,13 @@ def test_fast_bucket_path_equals_general_path():
         sk, sid = ops.bucket_sort(dev(k.view(np.int64)))
         gen = np.sort(u64(ops.emit_pairs(sk, sid, 4)))
         for T in (None, 9, 12, 16):                               # one- and two-pass partitions
-            fast = ops.emit_pairs_fast(dev(k.view(np.int64)), 4, part_bits=T)
-            assert fast is not None and fast.numel() == gen.size
-            assert np.array_equal(np.sort(u64(fast)), gen)
+            for kw in (dict(one_pass=False),                      # count-then-fill
+                       dict(),                                    # cursor-reserved ranges, default capacity guess
+                       dict(capacity=max(1, gen.size // 3)),      # guess too small: counted, retried exactly sized
+                       dict(capacity=gen.size)):                  # exact
+                fast = ops.emit_pairs_fast(dev(k.view(np.int64)), 4, part_bits=T, **kw)
+                assert fast is not None and fast.numel() == gen.size
+                assert np.array_equal(np.sort(u64(fast)), gen)
 
 
 def test_overflowing_part_falls_back_to_general_path():
