@@ -68,12 +68,13 @@ def algorithmic_bytes_per_step(w):
         "minhash": 4 * nnz + 8 * nq + (sb * P + 8 * b + 8) * nq,
         # partition pass of the bucket path: key in, key + id out
         "sort_scatter_kv": (8 + 12) * rec,
+        "part_scatter": (8 + 12) * rec,               # one-kernel partition (atomic room reservation per tile and part)
         "bucket_count": 12 * rec,
         "bucket_fill": 12 * rec + 8 * em,
         "bucket_emit": 12 * rec + 8 * em,             # one-pass form (cursor-reserved output ranges)
         # keys-only LSD passes: pair words, then directed edge keys
         "sort_scatter_k": 16 * (pair_passes * em + edge_passes * 2 * un),
-        "sort_hist": 8 * (rec + pair_passes * em + edge_passes * 2 * un),
+        "sort_hist": 8 * (pair_passes * em + edge_passes * 2 * un),
         # rows de-duplicated and ordered in LDS: emitted words in, distinct words out; then the gaps closed
         "row_unique": 8 * em + 8 * un,
         "row_unique_gather": 16 * un,

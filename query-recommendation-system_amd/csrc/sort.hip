@@ -501,6 +501,116 @@ __global__ __launch_bounds__(SORT_THREADS, 3) void part_scatter_staged_kernel(
   }
 }
 
+// One-kernel partition for the one-pass bucket path (256 parts): every part owns a fixed region of
+// `cap` records, a tile reserves room in each part with one atomicAdd per (tile, part) on the part's
+// cursor, and writes its records there through the same LDS staging as above.  No histogram pass, no
+// row scan, no bounds search; the order of the records inside a part is whatever the atomics gave
+// (the finish does not care).  A part that would exceed `cap` raises the overflow word and its
+// records are dropped -- the caller then takes the general path.
+__global__ __launch_bounds__(SORT_THREADS, 3) void part_scatter_atomic_kernel(
+    const uint64_t *__restrict__ keys_in, uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int64_t n,
+    int ntiles, int shift, uint32_t *__restrict__ cursors, uint32_t cap, uint32_t *__restrict__ overflow, uint64_t ek) {
+  __shared__ uint32_t cnt[SORT_THREADS / WAVE][RADIX];
+  __shared__ uint32_t lsum[SORT_THREADS / WAVE];
+  __shared__ uint32_t gdelta[RADIX];
+  __shared__ uint8_t gok[RADIX];
+  __shared__ uint64_t skey[SORT_TILE];
+  __shared__ uint32_t sval[SORT_TILE];
+  const int tile = xcd_tile(blockIdx.x, ntiles), batch = blockIdx.y;
+  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < SORT_THREADS / WAVE; ++i) cnt[i][threadIdx.x] = 0;
+  __syncthreads();
+  const size_t boff = (size_t)batch * n;
+  const int64_t tbase = (int64_t)tile * SORT_TILE;
+  const int64_t wbase = tbase + (int64_t)w * (WAVE * SORT_IPT);
+  uint64_t key[SORT_IPT];
+  uint32_t dr[SORT_IPT];
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int k = 0; k < SORT_IPT; ++k) {
+    const int64_t idx = wbase + (int64_t)k * WAVE + lane;
+    key[k] = idx < n ? keys_in[boff + idx] : 0;
+  }
+#pragma unroll
+  for (int k = 0; k < SORT_IPT; ++k) {
+    const int64_t idx = wbase + (int64_t)k * WAVE + lane;
+    const bool valid = idx < n;
+    const uint32_t d = part_digit<true>(key[k], idx, shift, ek, RADIX - 1);
+    uint64_t m = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+      const bool one = (d >> bit) & 1u;
+      const uint64_t bal = __ballot(one);
+      m &= one ? bal : ~bal;
+    }
+    const uint32_t below = (uint32_t)__popcll(m & lt_mask);
+    uint32_t prev = 0;
+    if (valid) {
+      prev = cnt[w][d];
+      if (below == 0) cnt[w][d] = prev + (uint32_t)__popcll(m);
+    }
+    dr[k] = (d << 16) | (prev + below);
+  }
+  __syncthreads();
+  {
+    const int d = threadIdx.x;
+    uint32_t tc = 0;
+#pragma unroll
+    for (int i = 0; i < SORT_THREADS / WAVE; ++i) tc += cnt[i][d];
+    // the reservation goes out first: its latency hides behind the scan below
+    const uint32_t gb = tc ? atomicAdd(&cursors[(size_t)batch * RADIX + d], tc) : 0u;
+    uint32_t linc = tc;
+#pragma unroll
+    for (int k = 1; k < WAVE; k <<= 1) {
+      const uint32_t lo = __shfl_up(linc, k, WAVE);
+      if (lane >= k) linc += lo;
+    }
+    if (lane == WAVE - 1) lsum[w] = linc;
+    __syncthreads();
+    uint32_t lstart = linc - tc;
+#pragma unroll
+    for (int k = 0; k < SORT_THREADS / WAVE; ++k)
+      if (k < w) lstart += lsum[k];
+    const bool ok = gb + tc <= cap;
+    if (!ok) atomicOr(overflow, 1u);
+    gok[d] = ok;
+    gdelta[d] = (uint32_t)d * cap + gb - lstart;  // mod 2^32; + the staged position gives the place in the batch
+    uint32_t run = lstart;
+#pragma unroll
+    for (int i = 0; i < SORT_THREADS / WAVE; ++i) {
+      const uint32_t c = cnt[i][d];
+      cnt[i][d] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < SORT_IPT; ++k) {
+    const int64_t idx = wbase + (int64_t)k * WAVE + lane;
+    if (idx < n) {
+      const uint32_t d = dr[k] >> 16, lp = cnt[w][d] + (dr[k] & 0xFFFFu);
+      skey[lp] = key[k];
+      sval[lp] = (uint32_t)idx | d << 24;
+    }
+  }
+  __syncthreads();
+  const int ntile = (int)min((int64_t)SORT_TILE, n - tbase);
+  const size_t obase = (size_t)batch * RADIX * cap;
+#pragma unroll
+  for (int k = 0; k < SORT_IPT; ++k) {
+    const int p = k * SORT_THREADS + threadIdx.x;
+    if (p < ntile) {
+      const uint32_t vv = sval[p], d = vv >> 24;
+      if (gok[d]) {
+        const size_t dst = obase + (uint32_t)(gdelta[d] + (uint32_t)p);
+        keys_out[dst] = skey[p];
+        vals_out[dst] = vv & 0xFFFFFFu;
+      }
+    }
+  }
+}
+
 QRLSH_EXPORT size_t qrlsh_sort_workspace_bytes(int64_t n, int32_t nbatch) {
   if (n <= 0 || nbatch <= 0) return 16;
   const int64_t ntiles = ceil_div64(n, SORT_TILE);
@@ -675,7 +785,9 @@ __global__ __launch_bounds__(FIN_THREADS, 8) void bucket_finish_kernel(const uin
                                                                        uint64_t *__restrict__ blk,
                                                                        uint32_t *__restrict__ overflow,
                                                                        uint64_t *__restrict__ out,
-                                                                       uint64_t capacity) {
+                                                                       uint64_t capacity,
+                                                                       const uint32_t *__restrict__ counts = nullptr,
+                                                                       uint32_t cap = 0) {
   constexpr bool FILL = MODE != FIN_COUNT;
   __shared__ unsigned long long gbase;
   __shared__ __attribute__((aligned(16))) unsigned long long tab[FIN_CAP];
@@ -683,10 +795,13 @@ __global__ __launch_bounds__(FIN_THREADS, 8) void bucket_finish_kernel(const uin
   __shared__ uint32_t wsum[FIN_THREADS / WAVE];
   const int part = blockIdx.x, band = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid >> 6;
-  const uint32_t start = starts[(size_t)band * (nparts + 1) + part];
-  const uint32_t m = starts[(size_t)band * (nparts + 1) + part + 1] - start;
   const size_t bslot = (size_t)band * nparts + part;
-  if (m > (uint32_t)FIN_CAP) {  // uniform over the workgroup
+  // records of the part: [start, start + m) of the band's nq sorted records, or (counts given) the first
+  // counts[part] records of the part's own region of cap records
+  const uint32_t start = counts ? 0u : starts[(size_t)band * (nparts + 1) + part];
+  const uint32_t m = counts ? counts[bslot] : starts[(size_t)band * (nparts + 1) + part + 1] - start;
+  const size_t first = counts ? bslot * cap : (size_t)band * nq + start;
+  if (m > (uint32_t)FIN_CAP || (counts && m > cap)) {  // uniform over the workgroup
     if (tid == 0) {
       atomicOr(overflow, 1u);
       if (MODE == FIN_COUNT) blk[bslot] = 0;
@@ -697,8 +812,8 @@ __global__ __launch_bounds__(FIN_THREADS, 8) void bucket_finish_kernel(const uin
     if (MODE == FIN_COUNT && tid == 0) blk[bslot] = 0;
     return;
   }
-  const uint64_t *k = keys + (size_t)band * nq + start;
-  const uint32_t *id = ids + (size_t)band * nq + start;
+  const uint64_t *k = keys + first;
+  const uint32_t *id = ids + first;
   uint64_t kreg[FIN_IPT];
   uint32_t ireg[FIN_IPT];
 #pragma unroll
@@ -934,6 +1049,22 @@ QRLSH_EXPORT int qrlsh_bucket_pairs_count(const uint64_t *keys, uint64_t *part_k
   return QRLSH_OK;
 }
 
+// records every part's region holds in the one-kernel partition (256 parts): the LDS image of the
+// finish for full-size inputs, mean + 50 % + 512 for small ones
+static uint32_t part_region(int64_t nq) {
+  const int64_t c = ((nq / RADIX) * 3 / 2 + 512 + 63) / 64 * 64;
+  return (uint32_t)(c < FIN_CAP ? c : FIN_CAP);
+}
+
+// words part_keys / part_ids must hold for qrlsh_bucket_pairs_emit
+QRLSH_EXPORT size_t qrlsh_bucket_part_words(int64_t nq, int32_t b, int32_t part_bits) {
+  if (nq <= 0 || b <= 0) return 0;
+  const size_t plain = (size_t)b * nq;
+  if (part_bits != 8 || nq > (1ll << 24)) return plain;
+  const size_t regions = (size_t)b * RADIX * part_region(nq);
+  return regions > plain ? regions : plain;
+}
+
 // One-pass form: partition + finish with the output range of every part reserved on a device cursor.
 // total_overflow_out[0] ends up holding the exact number of pairs whether or not they fitted
 // `capacity` words of pairs_out (nothing is written past it); [1] != 0 flags an oversized part.
@@ -950,6 +1081,25 @@ QRLSH_EXPORT int qrlsh_bucket_pairs_emit(const uint64_t *keys, uint64_t *part_ke
                (unsigned long long)capacity);
   const int nparts = 1 << part_bits;
   const BucketWs w = bucket_ws(workspace, nq, b, part_bits);
+  if (part_bits == 8 && nq <= (1ll << 24)) {
+    // one-kernel partition into fixed regions; the part cursors live where the general path keeps `starts`
+    const uint32_t cap = part_region(nq);
+    uint32_t *cursors = w.starts;
+    if (hipMemsetAsync(cursors, 0, (size_t)b * RADIX * sizeof(uint32_t), st) != hipSuccess) {
+      qrlsh_set_error("qrlsh_bucket_pairs_emit: hipMemsetAsync failed");
+      return QRLSH_EHIP;
+    }
+    const int ntiles = (int)ceil_div64(nq, SORT_TILE);
+    QR_LAUNCH("part_scatter", part_scatter_atomic_kernel, dim3(ntiles, b), dim3(SORT_THREADS), 0, st, keys, part_keys,
+              part_ids, nq, ntiles, 56, cursors, cap, reinterpret_cast<uint32_t *>(total_overflow_out + 1),
+              qr_empty_key(r));
+    QR_LAUNCH("bucket_emit", (bucket_finish_kernel<FIN_EMIT>), dim3(nparts, b), dim3(FIN_THREADS), 0, st,
+              (const uint64_t *)part_keys, (const uint32_t *)part_ids, nq, (const uint32_t *)nullptr, nparts,
+              qr_empty_key(r), total_overflow_out, reinterpret_cast<uint32_t *>(total_overflow_out + 1), pairs_out,
+              capacity, (const uint32_t *)cursors, cap);
+    QR_LAUNCH_CHECK("qrlsh_bucket_pairs_emit");
+    return QRLSH_OK;
+  }
   bucket_partition(keys, part_keys, part_ids, tmp_keys, tmp_ids, nq, b, r, part_bits, w, st);
   QR_LAUNCH("bucket_emit", (bucket_finish_kernel<FIN_EMIT>), dim3(nparts, b), dim3(FIN_THREADS), 0, st,
             (const uint64_t *)part_keys, (const uint32_t *)part_ids, nq, (const uint32_t *)w.starts, nparts,

@@ -333,8 +333,9 @@ def emit_pairs_fast(keys, r, part_bits=None, one_pass=True, capacity=None):
     T = part_bits if part_bits is not None else part_bits_for(nq)
     if nq > 6144 * (1 << T):
         return None  # cannot fit even with the finest partition
-    pk = torch.empty_like(keys)
-    pid = torch.empty((b, nq), dtype=torch.int32, device=dev)
+    words = lib.qrlsh_bucket_part_words(nq, b, T) if one_pass else b * nq
+    pk = torch.empty((words,), dtype=torch.int64, device=dev)
+    pid = torch.empty((words,), dtype=torch.int32, device=dev)
     tk = torch.empty_like(keys) if T > 8 else None
     tid = torch.empty((b, nq), dtype=torch.int32, device=dev) if T > 8 else None
     ws = _ws(lib.qrlsh_bucket_workspace_bytes(nq, b, T), dev)

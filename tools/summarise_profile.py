@@ -34,6 +34,7 @@ LABELS = [
     (r"^pairs_count_kernel", "pairs_count"), (r"^pairs_fill_kernel", "pairs_fill"),
     (r"^row_unique_kernel", "row_unique"), (r"^row_unique_gather_kernel", "row_unique_gather"),
     (r"^sort_scatter_staged_kernel", "sort_scatter_k"), (r"^part_scatter_staged_kernel", "sort_scatter_kv"),
+    (r"^part_scatter_atomic_kernel", "part_scatter"),
     (r"^compact_count_kernel<0>", "unique_count"), (r"^compact_fill_kernel<0>", "unique_fill"),
     (r"^compact_count_kernel<1>", "topk_count"), (r"^compact_fill_kernel<1>", "topk_fill"),
     (r"^score_pairs_kernel", "score_pairs"), (r"^scan_u64_kernel", "scan_blocks"), (r"^synth_kernel", "synth"),
