@@ -190,6 +190,7 @@ def main():
                  P=P, b=b, nnz=nnz, emitted=int(res.stats.get("emitted_pairs", 0)), unique=int(res.pairs.numel()),
                  kept=int(res.src.numel()), sig_bytes=2 if res.sig.dtype == torch.int16 else 4)
         ab = algorithmic_bytes_per_step(w)
+        sb_tab = 2 if D <= 65536 else 4
         traffic, traffic_src = load_traffic()
         kernels = {}
         for name, (cnt_, ms) in prof.items():   # summed over the prof_steps sampled steps of the timed region
@@ -214,6 +215,11 @@ def main():
             if dom in traffic:
                 roofline["traffic"] = int(traffic[dom]["hbm_bytes_per_launch"])
                 roofline["traffic_source"] = traffic_src
+            if dom == "minhash":
+                roofline["note"] = ("the kernel's work is the gather of |A(q)| rows x 2P bytes per signature from the "
+                                    "8 MB permutation table (%.2f GB per launch), which lives in L2 / Infinity Cache; "
+                                    "FETCH_SIZE counts the L2 misses the Infinity Cache serves, hence traffic > "
+                                    "algorithmic HBM bytes (DESIGN.md section 6)" % (nnz * P * sb_tab / 1e9))
 
         cpu_baseline = None
         recall = None

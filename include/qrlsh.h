@@ -163,8 +163,9 @@ int qrlsh_unique_fill(const uint64_t *sorted, int64_t n, const void *workspace, 
  * of the emitted i << 32 | j words: about half the passes of the full (i, j) sort): every row -- the
  * pairs of one i, tens of words -- is de-duplicated (hash set) and ordered by j in LDS.  Replaces the Python set of
  * lsh.py:41,53 like qrlsh_unique_*, same result.  count: tmp is scratch of n words; leaves {number of
- * unique pairs, overflow flag} in total_overflow_out[2] (device uint64 x2); overflow != 0 means one i
- * has more than ~1024 emitted pairs past a 2048-word chunk boundary: ignore the total and use the general
+ * unique pairs, overflow flag} in total_overflow_out[2] (device uint64 x2); rows that do not fit a
+ * workgroup's chunk image (more than ~1024 pairs past a 2048-word boundary) get a workgroup of their own;
+ * overflow != 0 means one i has more than 12288 emitted pairs: ignore the total and use the general
  * path (full qrlsh_sort_u64 + qrlsh_unique_*) on the same words.  fill follows a count on the same
  * tmp / workspace and writes exactly `total` words, ascending.
  */

@@ -119,7 +119,7 @@ static __global__ __launch_bounds__(1024) void scan_u64_kernel(uint64_t *__restr
   const int64_t per = (m + 1023) / 1024;
   const int64_t lo = min((int64_t)t * per, m), hi = min(lo + per, m);
   uint64_t s = 0;
-  constexpr int SCAN_REG = 16;  // up to 16 K elements: every load is issued before the first add
+  constexpr int SCAN_REG = 32;  // up to 32 K elements: every load is issued before the first add
   uint64_t held[SCAN_REG];
   const bool small = per <= SCAN_REG;
   if (small) {

@@ -347,7 +347,8 @@ __global__ __launch_bounds__(RD_THREADS) void row_unique_kernel(const uint64_t *
                                                                 uint64_t *__restrict__ tmp,
                                                                 uint64_t *__restrict__ counts,
                                                                 uint64_t *__restrict__ starts,
-                                                                uint64_t *__restrict__ overflow) {
+                                                                uint64_t *__restrict__ longlist,
+                                                                unsigned long long *__restrict__ nlong) {
   __shared__ uint32_t lo[RD_IMG];    // j of every word; later: the packed distinct values
   __shared__ uint32_t tab[RD_IMG];   // hash sets, one per owned row, over the row's own span
   __shared__ uint16_t rs[RD_IMG];    // row start + 1 of the row a word belongs to, 0 = row began before the image
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(RD_THREADS) void row_unique_kernel(const uint64_t *
   __shared__ uint16_t pre[RD_IMG + 1];  // occupied slots before position p
   __shared__ uint16_t crow[RD_IMG];  // row start of every packed value
   __shared__ uint32_t wsum[RD_THREADS / WAVE];
-  __shared__ uint32_t h0s, tail_open;
+  __shared__ uint32_t h0s, tail_open, long_s;
   const int t = threadIdx.x, lane = t & (WAVE - 1), w = t >> 6;
   const int64_t c0 = (int64_t)blockIdx.x * RD_C;
   const int m = (int)min((int64_t)RD_IMG, n - c0);
@@ -363,6 +364,7 @@ __global__ __launch_bounds__(RD_THREADS) void row_unique_kernel(const uint64_t *
   if (t == 0) {
     h0s = 0xFFFFFFFFu;
     tail_open = 0;
+    long_s = 0xFFFFFFFFu;
   }
   __syncthreads();
   // load; a word whose i differs from its predecessor's starts a row (i itself is not kept in LDS:
@@ -432,14 +434,17 @@ __global__ __launch_bounds__(RD_THREADS) void row_unique_kernel(const uint64_t *
     if (s1 == (uint32_t)p + 1u && p < mc) atomicMin(&h0s, (uint32_t)p);
     const bool last = p + 1 == m;
     if (last || rs[p + 1] == (uint16_t)(p + 2)) re[s1 - 1] = (uint16_t)(p + 1);
-    if (last && (int)s1 - 1 < mc && tail_open) atomicOr((unsigned long long *)overflow, 1ull);
+    // the last owned row runs past the image: it is left to row_unique_long_kernel (it is
+    // necessarily the LAST row that starts in this chunk, so its output follows this workgroup's)
+    if (last && (int)s1 - 1 < mc && tail_open) long_s = s1 - 1;
   }
   __syncthreads();
+  const int own_end = (int)min((uint32_t)mc, long_s);  // rows starting before this position are finished here
 
   // 1. hash-set insert of every owned word into its row's span of tab
   for (int p = t; p < m; p += RD_THREADS) {
     const uint32_t s1 = rs[p];
-    if (!s1 || (int)s1 - 1 >= mc) continue;
+    if (!s1 || (int)s1 - 1 >= own_end) continue;
     const uint32_t s = s1 - 1, e = re[s], len = e - s, v = lo[p];
     uint32_t slot = s + __umulhi(v * 0x9E3779B1u, len);
     for (;;) {  // at most len probes: the row has len slots and at most len distinct values
@@ -497,8 +502,104 @@ __global__ __launch_bounds__(RD_THREADS) void row_unique_kernel(const uint64_t *
     dst[cs + r] = (in[c0 + s] & 0xFFFFFFFF00000000ull) | v;
   }
   if (t == 0) {
-    counts[blockIdx.x] = total;
-    starts[blockIdx.x] = (uint64_t)(c0 + h0);
+    // two output segments per workgroup: its finished rows, then its long row (filled in later)
+    counts[2 * (size_t)blockIdx.x] = total;
+    starts[2 * (size_t)blockIdx.x] = (uint64_t)(c0 + h0);
+    counts[2 * (size_t)blockIdx.x + 1] = 0;
+    starts[2 * (size_t)blockIdx.x + 1] = (uint64_t)(c0 + (long_s == 0xFFFFFFFFu ? 0u : long_s));
+    if (long_s != 0xFFFFFFFFu)
+      longlist[__hip_atomic_fetch_add(nlong, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = blockIdx.x;
+  }
+}
+
+// Rows too long for the chunk image (an i with thousands of emitted pairs; rare): one 1024-thread
+// workgroup per row, same three steps with a table of RL_CAP slots.  The grid is fixed and walks the
+// list the main kernel left, so nothing is read back to size the launch.  A row above RL_CAP words
+// raises the overflow word (general path).
+constexpr int RL_THREADS = 1024;
+constexpr int RL_CAP = 12288;
+constexpr int RL_PER = RL_CAP / RL_THREADS;
+constexpr int RL_GRID = 512;
+
+__global__ __launch_bounds__(RL_THREADS) void row_unique_long_kernel(const uint64_t *__restrict__ in, int64_t n,
+                                                                     uint64_t *__restrict__ tmp,
+                                                                     uint64_t *__restrict__ counts,
+                                                                     const uint64_t *__restrict__ starts,
+                                                                     const uint64_t *__restrict__ longlist,
+                                                                     const unsigned long long *__restrict__ nlong,
+                                                                     uint64_t *__restrict__ overflow) {
+  __shared__ uint32_t tab[RL_CAP];
+  __shared__ uint32_t pk[RL_CAP];
+  __shared__ uint32_t wsum[RL_THREADS / WAVE];
+  __shared__ long long s_end;
+  const int t = threadIdx.x, lane = t & (WAVE - 1), w = t >> 6;
+  const unsigned long long nl = *nlong;
+  for (unsigned long long e = blockIdx.x; e < nl; e += gridDim.x) {
+    const uint64_t b = longlist[e];
+    const int64_t s0 = (int64_t)starts[2 * b + 1];
+    const uint64_t ihi = in[s0] & 0xFFFFFFFF00000000ull;
+    if (t == 0) {  // end of the row: first position whose i is larger (the words are ordered by i)
+      int64_t a = s0 + 1, z = n;
+      while (a < z) {
+        const int64_t mid = (a + z) >> 1;
+        if ((in[mid] & 0xFFFFFFFF00000000ull) > ihi) z = mid;
+        else a = mid + 1;
+      }
+      s_end = a;
+    }
+#pragma unroll
+    for (int k = 0; k < RL_PER; ++k) tab[t + k * RL_THREADS] = RD_EMPTY;
+    __syncthreads();
+    const int64_t len = s_end - s0;
+    if (len > RL_CAP) {  // uniform
+      if (t == 0) atomicOr((unsigned long long *)overflow, 1ull);
+      __syncthreads();
+      continue;
+    }
+    for (int64_t p = t; p < len; p += RL_THREADS) {
+      const uint32_t v = (uint32_t)in[s0 + p];
+      uint32_t slot = __umulhi(v * 0x9E3779B1u, (uint32_t)RL_CAP);
+      for (;;) {
+        const uint32_t old = atomicCAS(&tab[slot], RD_EMPTY, v);
+        if (old == RD_EMPTY || old == v) break;
+        slot = slot + 1 == (uint32_t)RL_CAP ? 0u : slot + 1;
+      }
+    }
+    __syncthreads();
+    // pack the distinct values
+    const int b0 = t * RL_PER;
+    uint32_t val[RL_PER], sum = 0;
+#pragma unroll
+    for (int k = 0; k < RL_PER; ++k) {
+      val[k] = tab[b0 + k];
+      sum += val[k] != RD_EMPTY;
+    }
+    uint32_t inc = sum;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+      const uint32_t o = __shfl_up(inc, d, WAVE);
+      if (lane >= d) inc += o;
+    }
+    if (lane == WAVE - 1) wsum[w] = inc;
+    __syncthreads();
+    uint32_t run = inc - sum, u = 0;
+    for (int k = 0; k < RL_THREADS / WAVE; ++k) {
+      if (k < w) run += wsum[k];
+      u += wsum[k];
+    }
+#pragma unroll
+    for (int k = 0; k < RL_PER; ++k)
+      if (val[k] != RD_EMPTY) pk[run++] = val[k];
+    __syncthreads();
+    for (uint32_t k = t; k < u; k += RL_THREADS) {
+      const uint32_t v = pk[k];
+      uint32_t r = 0;
+#pragma unroll 8
+      for (uint32_t q = 0; q < u; ++q) r += pk[q] < v;
+      tmp[s0 + r] = ihi | v;
+    }
+    if (t == 0) counts[2 * b + 1] = u;
+    __syncthreads();  // tab / pk / wsum / s_end are reused by the next row
   }
 }
 
@@ -507,14 +608,19 @@ __global__ __launch_bounds__(RD_THREADS) void row_unique_gather_kernel(const uin
                                                                        const uint64_t *__restrict__ offs,
                                                                        const uint64_t *__restrict__ starts,
                                                                        uint64_t *__restrict__ out) {
-  const uint64_t o0 = offs[blockIdx.x], cnt = offs[blockIdx.x + 1] - o0;
-  const uint64_t *src = tmp + starts[blockIdx.x];
-  for (uint32_t k = threadIdx.x; k < cnt; k += RD_THREADS) out[o0 + k] = src[k];
+#pragma unroll
+  for (int seg = 0; seg < 2; ++seg) {  // the workgroup's finished rows, then its long row (usually empty)
+    const size_t g = 2 * (size_t)blockIdx.x + seg;
+    const uint64_t o0 = offs[g], cnt = offs[g + 1] - o0;
+    const uint64_t *src = tmp + starts[g];
+    for (uint32_t k = threadIdx.x; k < cnt; k += RD_THREADS) out[o0 + k] = src[k];
+  }
 }
 
+// workspace: counts[2 nblk + 1] | starts[2 nblk] | longlist[nblk] | nlong
 QRLSH_EXPORT size_t qrlsh_row_unique_workspace_bytes(int64_t n) {
   const int64_t nblk = n > 0 ? ceil_div64(n, RD_C) : 0;
-  return (size_t)(2 * (nblk + 1)) * sizeof(uint64_t);
+  return (size_t)(5 * nblk + 2) * sizeof(uint64_t);
 }
 
 QRLSH_EXPORT int qrlsh_row_unique_count(const uint64_t *grouped, int64_t n, uint64_t *tmp, void *workspace,
@@ -533,14 +639,19 @@ QRLSH_EXPORT int qrlsh_row_unique_count(const uint64_t *grouped, int64_t n, uint
     return QRLSH_EWORKSPACE;
   }
   const int64_t nblk = ceil_div64(n, RD_C);
-  uint64_t *counts = static_cast<uint64_t *>(workspace), *starts = counts + (nblk + 1);
-  if (hipMemsetAsync(counts + nblk, 0, sizeof(uint64_t), st) != hipSuccess) {
+  uint64_t *counts = static_cast<uint64_t *>(workspace), *starts = counts + (2 * nblk + 1);
+  uint64_t *longlist = starts + 2 * nblk, *nlong = longlist + nblk;
+  if (hipMemsetAsync(counts + 2 * nblk, 0, sizeof(uint64_t), st) != hipSuccess ||
+      hipMemsetAsync(nlong, 0, sizeof(uint64_t), st) != hipSuccess) {
     qrlsh_set_error("qrlsh_row_unique_count: hipMemsetAsync failed");
     return QRLSH_EHIP;
   }
   QR_LAUNCH("row_unique", row_unique_kernel, dim3((unsigned)nblk), dim3(RD_THREADS), 0, st, grouped, n, tmp, counts,
-            starts, total_overflow_out + 1);
-  QR_LAUNCH("scan_blocks", scan_u64_kernel, dim3(1), dim3(1024), 0, st, counts, nblk + 1, total_overflow_out);
+            starts, longlist, reinterpret_cast<unsigned long long *>(nlong));
+  QR_LAUNCH("row_unique_long", row_unique_long_kernel, dim3((unsigned)(nblk < RL_GRID ? nblk : RL_GRID)),
+            dim3(RL_THREADS), 0, st, grouped, n, tmp, counts, (const uint64_t *)starts, (const uint64_t *)longlist,
+            (const unsigned long long *)nlong, total_overflow_out + 1);
+  QR_LAUNCH("scan_blocks", scan_u64_kernel, dim3(1), dim3(1024), 0, st, counts, 2 * nblk + 1, total_overflow_out);
   QR_LAUNCH_CHECK("qrlsh_row_unique_count");
   return QRLSH_OK;
 }
@@ -551,7 +662,7 @@ QRLSH_EXPORT int qrlsh_row_unique_fill(const uint64_t *tmp, int64_t n, const voi
   if (n == 0) return QRLSH_OK;
   QR_CHECK_ARG(tmp && workspace && out, "qrlsh_row_unique_fill: null pointer");
   const int64_t nblk = ceil_div64(n, RD_C);
-  const uint64_t *offs = static_cast<const uint64_t *>(workspace), *starts = offs + (nblk + 1);
+  const uint64_t *offs = static_cast<const uint64_t *>(workspace), *starts = offs + (2 * nblk + 1);
   QR_LAUNCH("row_unique_gather", row_unique_gather_kernel, dim3((unsigned)nblk), dim3(RD_THREADS), 0,
             static_cast<hipStream_t>(stream), tmp, offs, starts, out);
   QR_LAUNCH_CHECK("qrlsh_row_unique_fill");

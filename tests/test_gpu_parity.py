@@ -150,7 +150,7 @@ def _rows_case(rng, nq, lens, jmax, dup):
 
 
 @pytest.mark.parametrize("id_bits", [20, 32])
-@pytest.mark.parametrize("case", ["short", "mixed", "chunk_edges", "one_row", "tiny", "empty"])
+@pytest.mark.parametrize("case", ["short", "mixed", "long_rows", "chunk_edges", "one_row", "tiny", "empty"])
 def test_row_unique_equals_sorted_set(case, id_bits):
     """qrlsh_row_unique_* (rows de-duplicated and ordered in LDS) == np.unique of the same words"""
     rng = np.random.default_rng(11)
@@ -159,6 +159,11 @@ def test_row_unique_equals_sorted_set(case, id_bits):
     elif case == "mixed":
         lens = rng.poisson(12, size=8000)
         lens[rng.integers(0, 8000, size=40)] = rng.integers(300, 1000, size=40)
+    elif case == "long_rows":            # rows past the chunk image go to the one-workgroup-per-row kernel
+        lens = rng.poisson(9, size=6000)
+        lens[rng.integers(0, 6000, size=25)] = rng.integers(1025, 12288, size=25)
+        lens[[0, 5999]] = [12288, 3000]
+        lens[3000:3003] = [5000, 4000, 2049]     # back to back
     elif case == "chunk_edges":          # rows of exactly the chunk size and its neighbours, back to back
         lens = np.array([1024, 1, 1023, 1024, 1024, 2, 1020, 5, 1000, 1024, 23, 1024, 1] * 3)
     elif case == "one_row":
@@ -176,7 +181,7 @@ def test_row_unique_equals_sorted_set(case, id_bits):
 def test_row_unique_reports_overflow_and_unique_pairs_falls_back():
     rng = np.random.default_rng(12)
     lens = rng.poisson(10, size=3000)
-    lens[1500] = 6000                     # one i with far more emitted pairs than the LDS image holds
+    lens[1500] = 20000                    # one i with more emitted pairs than even the long-row kernel's table holds
     words = _rows_case(rng, len(lens), lens, 1 << 20, dup=3)
     assert ops.row_unique(dev(words.view(np.int64))) is None
     shuffled = words[rng.permutation(len(words))]
