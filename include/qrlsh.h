@@ -162,7 +162,10 @@ int qrlsh_unique_fill(const uint64_t *sorted, int64_t n, const void *workspace, 
 /* Sorted unique pairs from pairs that are only GROUPED BY i (qrlsh_sort_u64 over bits [32, 32 + id_bits)
  * of the emitted i << 32 | j words: about half the passes of the full (i, j) sort): every row -- the
  * pairs of one i, tens of words -- is de-duplicated (hash set) and ordered by j in LDS.  Replaces the Python set of
- * lsh.py:41,53 like qrlsh_unique_*, same result.  count: tmp is scratch of n words; leaves {number of
+ * lsh.py:41,53 like qrlsh_unique_*, same result.  group_bits > 0: the words are ordered by
+ * i >> group_bits only (a row is then 2^group_bits consecutive i; every id < 2^id_bits and group_bits +
+ * id_bits <= 32) -- at 2^20 ids that is two radix passes instead of three.  count: tmp is scratch of n
+ * words; leaves {number of
  * unique pairs, overflow flag} in total_overflow_out[2] (device uint64 x2); rows that do not fit a
  * workgroup's chunk image (more than ~1024 pairs past a 2048-word boundary) get a workgroup of their own;
  * overflow != 0 means one i has more than 12288 emitted pairs: ignore the total and use the general
@@ -170,8 +173,9 @@ int qrlsh_unique_fill(const uint64_t *sorted, int64_t n, const void *workspace, 
  * tmp / workspace and writes exactly `total` words, ascending.
  */
 size_t qrlsh_row_unique_workspace_bytes(int64_t n);
-int qrlsh_row_unique_count(const uint64_t *grouped, int64_t n, uint64_t *tmp, void *workspace,
-                           size_t workspace_bytes, uint64_t *total_overflow_out, void *stream);
+int qrlsh_row_unique_count(const uint64_t *grouped, int64_t n, int32_t group_bits, int32_t id_bits,
+                           uint64_t *tmp, void *workspace, size_t workspace_bytes, uint64_t *total_overflow_out,
+                           void *stream);
 int qrlsh_row_unique_fill(const uint64_t *tmp, int64_t n, const void *workspace, uint64_t *out, void *stream);
 
 /* ---- a5: pair scoring ------------------------------------------------------------

@@ -336,6 +336,24 @@ QRLSH_EXPORT int qrlsh_unique_fill(const uint64_t *sorted, int64_t n, const void
 // workgroup are written, in order, into `tmp` starting at its first owned word (owned ranges
 // tile the input, so these never overlap); per-workgroup counts are scanned and a second small
 // kernel closes the gaps.
+// A "row" may also be a GROUP of 2^gbits consecutive i (the words are then ordered by i >> gbits only,
+// which can save the grouping sort its last pass): the value that is de-duplicated and ordered inside
+// a row is then (i's low gbits, j) packed into 32 bits, j < 2^jbits.
+struct RowSplit {
+  int gbits, jbits;
+  __device__ uint32_t row(uint64_t x) const { return (uint32_t)(x >> (32 + gbits)); }
+  __device__ uint32_t val(uint64_t x) const {
+    const uint32_t j = (uint32_t)x;
+    return gbits ? ((uint32_t)(x >> 32) & ((1u << gbits) - 1u)) << jbits | j : j;
+  }
+  // the word of value v in the row that word x0 belongs to
+  __device__ uint64_t word(uint64_t x0, uint32_t v) const {
+    if (!gbits) return (x0 & 0xFFFFFFFF00000000ull) | v;
+    const uint64_t i = ((x0 >> 32) & ~(uint64_t)((1u << gbits) - 1u)) | (v >> jbits);
+    return i << 32 | (v & ((1u << jbits) - 1u));
+  }
+};
+
 constexpr int RD_THREADS = 512;
 constexpr int RD_C = 2048;
 constexpr int RD_CAP = 1024;
@@ -348,7 +366,8 @@ __global__ __launch_bounds__(RD_THREADS) void row_unique_kernel(const uint64_t *
                                                                 uint64_t *__restrict__ counts,
                                                                 uint64_t *__restrict__ starts,
                                                                 uint64_t *__restrict__ longlist,
-                                                                unsigned long long *__restrict__ nlong) {
+                                                                unsigned long long *__restrict__ nlong, int gbits,
+                                                                int jbits) {
   __shared__ uint32_t lo[RD_IMG];    // j of every word; later: the packed distinct values
   __shared__ uint32_t tab[RD_IMG];   // hash sets, one per owned row, over the row's own span
   __shared__ uint16_t rs[RD_IMG];    // row start + 1 of the row a word belongs to, 0 = row began before the image
@@ -358,6 +377,7 @@ __global__ __launch_bounds__(RD_THREADS) void row_unique_kernel(const uint64_t *
   __shared__ uint32_t wsum[RD_THREADS / WAVE];
   __shared__ uint32_t h0s, tail_open, long_s;
   const int t = threadIdx.x, lane = t & (WAVE - 1), w = t >> 6;
+  const RowSplit rsp{gbits, jbits};
   const int64_t c0 = (int64_t)blockIdx.x * RD_C;
   const int m = (int)min((int64_t)RD_IMG, n - c0);
   const int mc = min(RD_C, m);
@@ -386,16 +406,16 @@ __global__ __launch_bounds__(RD_THREADS) void row_unique_kernel(const uint64_t *
 #pragma unroll
     for (int k = 0; k < RD_PER; ++k) {
       const int p = k * RD_THREADS + t;
-      const uint32_t h = (uint32_t)(x[k] >> 32);
+      const uint32_t h = rsp.row(x[k]);
       const uint32_t ph = __shfl_up(h, 1, WAVE);
       if (p < m) {
-        lo[p] = (uint32_t)x[k];
+        lo[p] = rsp.val(x[k]);
         tab[p] = RD_EMPTY;
-        const bool head = lane == 0 ? (c0 + p == 0 || (uint32_t)(xp[k] >> 32) != h) : ph != h;
+        const bool head = lane == 0 ? (c0 + p == 0 || rsp.row(xp[k]) != h) : ph != h;
         rs[p] = head ? (uint16_t)(p + 1) : (uint16_t)0;
       }
     }
-    if (more && (xlast >> 32) == (xnext >> 32)) tail_open = 1;
+    if (more && rsp.row(xlast) == rsp.row(xnext)) tail_open = 1;
   }
   __syncthreads();
 
@@ -499,7 +519,7 @@ __global__ __launch_bounds__(RD_THREADS) void row_unique_kernel(const uint64_t *
     const uint32_t s = crow[k], cs = pre[s], ce = pre[re[s]], v = lo[k];
     uint32_t r = 0;
     for (uint32_t q = cs; q < ce; ++q) r += lo[q] < v;
-    dst[cs + r] = (in[c0 + s] & 0xFFFFFFFF00000000ull) | v;
+    dst[cs + r] = rsp.word(in[c0 + s], v);
   }
   if (t == 0) {
     // two output segments per workgroup: its finished rows, then its long row (filled in later)
@@ -527,22 +547,25 @@ __global__ __launch_bounds__(RL_THREADS) void row_unique_long_kernel(const uint6
                                                                      const uint64_t *__restrict__ starts,
                                                                      const uint64_t *__restrict__ longlist,
                                                                      const unsigned long long *__restrict__ nlong,
-                                                                     uint64_t *__restrict__ overflow) {
+                                                                     uint64_t *__restrict__ overflow, int gbits,
+                                                                     int jbits) {
   __shared__ uint32_t tab[RL_CAP];
   __shared__ uint32_t pk[RL_CAP];
   __shared__ uint32_t wsum[RL_THREADS / WAVE];
   __shared__ long long s_end;
   const int t = threadIdx.x, lane = t & (WAVE - 1), w = t >> 6;
   const unsigned long long nl = *nlong;
+  const RowSplit rsp{gbits, jbits};
   for (unsigned long long e = blockIdx.x; e < nl; e += gridDim.x) {
     const uint64_t b = longlist[e];
     const int64_t s0 = (int64_t)starts[2 * b + 1];
-    const uint64_t ihi = in[s0] & 0xFFFFFFFF00000000ull;
-    if (t == 0) {  // end of the row: first position whose i is larger (the words are ordered by i)
+    const uint64_t x0 = in[s0];
+    if (t == 0) {  // end of the row: first position whose row id is larger (the words are ordered by it)
+      const uint32_t r0 = rsp.row(x0);
       int64_t a = s0 + 1, z = n;
       while (a < z) {
         const int64_t mid = (a + z) >> 1;
-        if ((in[mid] & 0xFFFFFFFF00000000ull) > ihi) z = mid;
+        if (rsp.row(in[mid]) > r0) z = mid;
         else a = mid + 1;
       }
       s_end = a;
@@ -557,7 +580,7 @@ __global__ __launch_bounds__(RL_THREADS) void row_unique_long_kernel(const uint6
       continue;
     }
     for (int64_t p = t; p < len; p += RL_THREADS) {
-      const uint32_t v = (uint32_t)in[s0 + p];
+      const uint32_t v = rsp.val(in[s0 + p]);
       uint32_t slot = __umulhi(v * 0x9E3779B1u, (uint32_t)RL_CAP);
       for (;;) {
         const uint32_t old = atomicCAS(&tab[slot], RD_EMPTY, v);
@@ -596,7 +619,7 @@ __global__ __launch_bounds__(RL_THREADS) void row_unique_long_kernel(const uint6
       uint32_t r = 0;
 #pragma unroll 8
       for (uint32_t q = 0; q < u; ++q) r += pk[q] < v;
-      tmp[s0 + r] = ihi | v;
+      tmp[s0 + r] = rsp.word(x0, v);
     }
     if (t == 0) counts[2 * b + 1] = u;
     __syncthreads();  // tab / pk / wsum / s_end are reused by the next row
@@ -623,9 +646,14 @@ QRLSH_EXPORT size_t qrlsh_row_unique_workspace_bytes(int64_t n) {
   return (size_t)(5 * nblk + 2) * sizeof(uint64_t);
 }
 
-QRLSH_EXPORT int qrlsh_row_unique_count(const uint64_t *grouped, int64_t n, uint64_t *tmp, void *workspace,
-                                        size_t workspace_bytes, uint64_t *total_overflow_out, void *stream) {
+QRLSH_EXPORT int qrlsh_row_unique_count(const uint64_t *grouped, int64_t n, int32_t group_bits, int32_t id_bits,
+                                        uint64_t *tmp, void *workspace, size_t workspace_bytes,
+                                        uint64_t *total_overflow_out, void *stream) {
   QR_CHECK_ARG(n >= 0 && total_overflow_out, "qrlsh_row_unique_count: bad arguments");
+  QR_CHECK_ARG(group_bits >= 0 && group_bits <= 8 && id_bits >= 1 && id_bits <= 32 &&
+                   (group_bits == 0 || group_bits + id_bits <= 32),
+               "qrlsh_row_unique_count: group_bits=%d / id_bits=%d (need group_bits + id_bits <= 32)", group_bits,
+               id_bits);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (hipMemsetAsync(total_overflow_out, 0, 2 * sizeof(uint64_t), st) != hipSuccess) {
     qrlsh_set_error("qrlsh_row_unique_count: hipMemsetAsync failed");
@@ -647,10 +675,10 @@ QRLSH_EXPORT int qrlsh_row_unique_count(const uint64_t *grouped, int64_t n, uint
     return QRLSH_EHIP;
   }
   QR_LAUNCH("row_unique", row_unique_kernel, dim3((unsigned)nblk), dim3(RD_THREADS), 0, st, grouped, n, tmp, counts,
-            starts, longlist, reinterpret_cast<unsigned long long *>(nlong));
+            starts, longlist, reinterpret_cast<unsigned long long *>(nlong), group_bits, id_bits);
   QR_LAUNCH("row_unique_long", row_unique_long_kernel, dim3((unsigned)(nblk < RL_GRID ? nblk : RL_GRID)),
             dim3(RL_THREADS), 0, st, grouped, n, tmp, counts, (const uint64_t *)starts, (const uint64_t *)longlist,
-            (const unsigned long long *)nlong, total_overflow_out + 1);
+            (const unsigned long long *)nlong, total_overflow_out + 1, group_bits, id_bits);
   QR_LAUNCH("scan_blocks", scan_u64_kernel, dim3(1), dim3(1024), 0, st, counts, 2 * nblk + 1, total_overflow_out);
   QR_LAUNCH_CHECK("qrlsh_row_unique_count");
   return QRLSH_OK;

@@ -51,7 +51,7 @@ SIGNATURES = {
     "qrlsh_bucket_pairs_emit": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp, _u64, _vp, _vp]),
     "qrlsh_compact_workspace_bytes": (_sz, [_i64]),
     "qrlsh_row_unique_workspace_bytes": (_sz, [_i64]),
-    "qrlsh_row_unique_count": (ctypes.c_int, [_vp, _i64, _vp, _vp, _sz, _vp, _vp]),
+    "qrlsh_row_unique_count": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _sz, _vp, _vp]),
     "qrlsh_row_unique_fill": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp]),
     "qrlsh_unique_count": (ctypes.c_int, [_vp, _i64, _vp, _sz, _vp, _vp]),
     "qrlsh_unique_fill": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp]),

@@ -43,8 +43,9 @@ class HipBackend:
     def sort_unique(self, words, bit_ranges):
         # bit_ranges = [(0, ib), (32, 32 + ib)]: pair words i << 32 | j
         ib = bit_ranges[0][1]
-        grouped, _ = ops.sort_u64(words, None, 32, 32 + ib)      # by i only; rows are finished in LDS
-        pairs = ops.row_unique(grouped)
+        g = ops.row_group_bits(ib)
+        grouped, _ = ops.sort_u64(words, None, 32 + g, 32 + ib)  # by i >> g only; rows are finished in LDS
+        pairs = ops.row_unique(grouped, g, ib)
         if pairs is None:                                        # a row too long for the LDS image
             words, _ = ops.sort_u64(grouped, None, 0, 2 * ib, fold=ib)
             pairs = ops.unique_sorted(words)

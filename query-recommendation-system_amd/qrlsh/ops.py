@@ -269,15 +269,23 @@ def sort_pairs(pairs, nq):
     return p
 
 
-def group_pairs_by_i(pairs, nq):
-    """pairs i<<32|j ordered by i only (j in arbitrary order inside a row): ceil(id_bits / 8) passes"""
-    p, _ = sort_u64(pairs, None, 32, 32 + id_bits_for(nq))
+def row_group_bits(id_bits):
+    """low bits of i the grouping sort may ignore (rows of 2^g consecutive i, finished in LDS) when that
+    saves its last 8-bit pass: the id bits left over above a multiple of 8, if at most 4"""
+    g = id_bits % 8
+    return g if (id_bits > 8 and 0 < g <= 4) else 0
+
+
+def group_pairs_by_i(pairs, nq, group_bits=0):
+    """pairs i<<32|j ordered by i >> group_bits only (arbitrary order inside a row)"""
+    p, _ = sort_u64(pairs, None, 32 + group_bits, 32 + id_bits_for(nq))
     return p
 
 
-def row_unique(grouped):
-    """Sorted unique pairs from pairs grouped by i (group_pairs_by_i); None when a row is too long
-    for the LDS image (skewed data) -- use unique_sorted(sort_pairs(...)) then."""
+def row_unique(grouped, group_bits=0, id_bits=32):
+    """Sorted unique pairs from pairs grouped by i >> group_bits (group_pairs_by_i); None when a row is
+    too long even for the one-row-per-workgroup kernel (heavily skewed data) -- use
+    unique_sorted(sort_pairs(...)) then."""
     lib = _lib.load()
     _need(grouped, torch.int64, "grouped", 1)
     n = grouped.numel()
@@ -287,7 +295,8 @@ def row_unique(grouped):
     tmp = torch.empty_like(grouped)
     ws = _ws(lib.qrlsh_row_unique_workspace_bytes(n), dev)
     tot = torch.empty(2, dtype=torch.int64, device=dev)
-    _lib.check(lib.qrlsh_row_unique_count(_ptr(grouped), n, _ptr(tmp), _ptr(ws), ws.numel(), _ptr(tot), _stream()))
+    _lib.check(lib.qrlsh_row_unique_count(_ptr(grouped), n, int(group_bits), int(id_bits), _ptr(tmp), _ptr(ws),
+                                          ws.numel(), _ptr(tot), _stream()))
     total, overflow = tot.tolist()
     if overflow:
         return None
@@ -298,8 +307,10 @@ def row_unique(grouped):
 
 def unique_pairs(emitted, nq, stats=None):
     """the Python set of lsh.py:41,53: sorted unique words of the emitted pairs (consumed)"""
-    grouped = group_pairs_by_i(emitted, nq)
-    pairs = row_unique(grouped)
+    ib = id_bits_for(nq)
+    g = row_group_bits(ib)
+    grouped = group_pairs_by_i(emitted, nq, g)
+    pairs = row_unique(grouped, g, ib)
     if stats is not None:
         stats["dedup_path"] = "rows-in-lds" if pairs is not None else "full-sort"
     if pairs is None:

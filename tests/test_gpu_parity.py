@@ -176,6 +176,15 @@ def test_row_unique_equals_sorted_set(case, id_bits):
     got = ops.row_unique(dev(words.view(np.int64)))
     assert got is not None
     assert np.array_equal(u64(got), np.unique(words))
+    if id_bits == 20 and case not in ("long_rows", "chunk_edges"):   # (those would outgrow the long-row table)
+        # rows = groups of 2^g consecutive i, in any order of i inside the group
+        for g in (1, 4):
+            order = np.argsort((words >> np.uint64(32 + g)), kind="stable")
+            blocks = words[order]
+            sh = rng.permutation(len(blocks))     # shuffle inside groups: sort the shuffled words by group only
+            blocks = blocks[sh][np.argsort((blocks[sh] >> np.uint64(32 + g)), kind="stable")]
+            got = ops.row_unique(dev(blocks.view(np.int64)), g, 20)
+            assert got is not None and np.array_equal(u64(got), np.unique(words)), g
 
 
 def test_row_unique_reports_overflow_and_unique_pairs_falls_back():
