@@ -10,9 +10,16 @@ Rank g owns the contiguous query range [g*nql, (g+1)*nql) and bands {k : k // ce
                      b/W * nq_total * 8 bytes instead of b * nq_total * 8;
        "all_gather": every rank receives every band key (the exchange BASELINE.json's
                      north_star names), then keeps its bands.
-  3. signature rows (compact uint16 when lossless) and norms start an ASYNC all-gather on a
-     second communicator: they are only needed for scoring, so the transfer runs beside
-     steps 4-5 instead of ahead of the short exchanges.
+  3. signatures for scoring.  An owner scores pairs (i local, j anywhere), so it needs the signature
+     rows of the j that live on other ranks.  Two ways, identical results:
+       "fetch" : after step 5 the owner asks the owning ranks for exactly the distinct remote j of
+                 its pairs (ids out, rows + norms back: two all-to-alls).  With p pairs per rank
+                 that is at most p rows however large the world is -- a third of the gather's
+                 volume at 8 ranks on the bench workload, most of it at 2;
+       "all_gather": every rank receives every row ((W-1)/W * nq_total * 2P bytes per rank) on a
+                 second communicator, asynchronously, beside steps 4-5.
+     "auto" (default) fetches unless the distinct remote rows of some rank exceed half of what the
+     all-gather would bring it.
   4. per owned band: bucket partition + pair emission over ALL queries; sorted by i only.
   5. pairs go to the owner of their smaller query id (variable-size all-to-all); the owner
      sorts + uniques what it received -> its share of the global candidate set.
@@ -62,12 +69,12 @@ class HipBackend:
         """one stable pass that orders words (and vals) by (word >> lo) // shard"""
         return ops.sort_u64(words, vals, lo, lo + 1, owner_shard=shard)
 
-    def verify(self, sig_all, b, pairs):
-        return ops.drop_unverified(sig_all, b, pairs)
+    def score_only(self, sig_rows, norm_rows, pairs):
+        """milli of pairs whose two halves index rows of sig_rows"""
+        return ops.score_pairs(sig_rows, norm_rows, pairs)[0]
 
-    def score(self, sig_all, norm_all, pairs, id_bits, wide=False):
-        milli, _, edges = ops.score_pairs(sig_all, norm_all, pairs, edge_id_bits=id_bits, wide=wide)
-        return milli, edges
+    def verify_flags(self, sig_rows, b, pairs):
+        return ops.verify_pairs(sig_rows, b, pairs)
 
     def sort_words_kv(self, words, vals, lo, hi):
         return ops.sort_u64(words, vals, lo, hi)
@@ -131,7 +138,7 @@ def _all_to_all(out, inp, osplit=None, isplit=None, group=None):
     dist.all_to_all_single(out, inp, output_split_sizes=osplit, input_split_sizes=isplit, group=group)
 
 
-def _exchange_var(chunks_sizes, send, group=None):
+def _exchange_var(chunks_sizes, send, group=None, want_sizes=False):
     """variable-size all-to-all of a 1-D int64 tensor already ordered by destination.
     chunks_sizes: python list of per-destination element counts."""
     world = dist.get_world_size(group)
@@ -142,11 +149,34 @@ def _exchange_var(chunks_sizes, send, group=None):
     rs = rsizes.tolist()
     recv = torch.empty(int(sum(rs)), dtype=send.dtype, device=dev)
     _all_to_all(recv, send, rs, list(chunks_sizes), group)
-    return recv
+    return (recv, rs) if want_sizes else recv
+
+
+def _fetch_rows(sig, norm2, need, nql, group=None):
+    """Signature rows + norms of the global query ids `need` (int64, ascending, none of them local):
+    ids go to the ranks that own them, rows and norms come back in the same order.  One payload per
+    row: its signature bytes followed by the 8 bytes of its norm."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = sig.device
+    bounds = torch.arange(world + 1, dtype=torch.int64, device=dev) * nql
+    cuts = torch.searchsorted(need, bounds).tolist()
+    sizes = [cuts[g + 1] - cuts[g] for g in range(world)]
+    req, rs = _exchange_var(sizes, need, group, want_sizes=True)
+    local = req - rank * nql
+    rowbytes = sig.shape[1] * sig.element_size()
+    out = torch.empty((local.numel(), rowbytes + 8), dtype=torch.uint8, device=dev)
+    out[:, :rowbytes] = sig.index_select(0, local).view(torch.uint8).view(local.numel(), rowbytes)
+    out[:, rowbytes:] = norm2.index_select(0, local).view(torch.uint8).view(local.numel(), 8)
+    got = torch.empty((need.numel(), rowbytes + 8), dtype=torch.uint8, device=dev)
+    _all_to_all(got, out, sizes, rs, group)
+    rows = got[:, :rowbytes].contiguous().view(sig.dtype).view(need.numel(), sig.shape[1])
+    norms = got[:, rowbytes:].contiguous().view(torch.int64).view(need.numel())
+    return rows, norms
 
 
 def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="all_to_all", backend=None,
-                               group=None, wide_ids=None):
+                               group=None, wide_ids=None, sig_exchange="auto"):
     """Hot path for this rank's query shard; collective over `group`.  Every rank must hold
     the same number of queries (nq_total % world == 0).  Returns a HotPathResult whose pairs /
     top-K rows are this rank's share (global query ids); concatenated over ranks in rank
@@ -188,13 +218,18 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
         raise ValueError("exchange must be 'all_to_all' or 'all_gather'")
     del keys
 
-    # 3. async gather of the signature rows + norms on the background communicator (consumed in
-    #    step 6; overlaps steps 4-5)
-    bg = background_group(group)
-    sig_all = torch.empty((nq_total, P), dtype=sig.dtype, device=dev)
-    norm_all = torch.empty((nq_total,), dtype=torch.int64, device=dev)
-    h_sig = _all_gather(sig_all, sig, bg, async_op=True)
-    h_nrm = _all_gather(norm_all, norm2, bg, async_op=True)
+    # 3. "all_gather": async gather of the signature rows + norms on the background communicator
+    #    (consumed in step 6; overlaps steps 4-5).  "fetch" / "auto": nothing yet, see step 6.
+    if sig_exchange not in ("auto", "fetch", "all_gather"):
+        raise ValueError("sig_exchange must be 'auto', 'fetch' or 'all_gather'")
+
+    def start_gather():
+        bg = background_group(group)
+        sa = torch.empty((nq_total, P), dtype=sig.dtype, device=dev)
+        na = torch.empty((nq_total,), dtype=torch.int64, device=dev)
+        return sa, na, _all_gather(sa, sig, bg, async_op=True), _all_gather(na, norm2, bg, async_op=True)
+
+    gathered = start_gather() if sig_exchange == "all_gather" else None
 
     # 4. candidates of the owned bands over all queries
     pair_bits = [(0, ib), (32, 32 + ib)]
@@ -214,16 +249,43 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
     pairs = be.sort_unique(got, pair_bits) if got.numel() else got
 
     # 6. score on the owner; reverse edges -> owner of j
-    h_sig.wait()
-    h_nrm.wait()
+    q0 = rank * nql
+    pi, pj = pairs >> 32, pairs & 0xFFFFFFFF
+    if gathered is None:
+        # which rows of other ranks do my pairs touch?  (i is local by construction)
+        remote = (pj < q0) | (pj >= q0 + nql)
+        need = torch.unique(pj[remote])                     # ascending
+        if sig_exchange == "auto" and world > 1:
+            most = torch.tensor([need.numel()], dtype=torch.int64, device=dev)
+            if _staged(most, group):
+                most = most.cpu()
+            dist.all_reduce(most, op=dist.ReduceOp.MAX, group=group)
+            if int(most.item()) * 2 > (world - 1) * nql:    # not a sliver: the plain gather moves less
+                gathered = start_gather()
+    stats["sig_exchange"] = "all_gather" if gathered is not None else "fetch"
+    if gathered is not None:
+        sig_rows, norm_rows, h_sig, h_nrm = gathered
+        h_sig.wait()
+        h_nrm.wait()
+        local_pairs = pairs                                  # row index == global query id
+    else:
+        if world > 1:
+            rrows, rnorms = _fetch_rows(sig, norm2, need, nql, group)
+        stats["remote_rows_fetched"] = int(need.numel())
+        sig_rows = torch.cat([sig, rrows]) if need.numel() else sig
+        norm_rows = torch.cat([norm2, rnorms]) if need.numel() else norm2
+        slot = torch.where(remote, nql + torch.searchsorted(need, pj), pj - q0) if need.numel() else pj - q0
+        local_pairs = ((pi - q0) << 32) | slot               # both halves index rows of sig_rows
     if r > 4 and pairs.numel():   # wide bands: hashed bucket ids -> exact verification on the owner
-        pairs = be.verify(sig_all, b, pairs)
-    milli, edges = be.score(sig_all, norm_all, pairs, ib, wide)
+        keep = be.verify_flags(sig_rows, b, local_pairs).bool()
+        if not bool(keep.all()):
+            pairs, local_pairs, pi, pj = pairs[keep], local_pairs[keep], pi[keep], pj[keep]
+    milli = be.score_only(sig_rows, norm_rows, local_pairs)
+    inv = (1000 - milli).to(torch.int64)
     if wide:
         # key + payload edges (src << 11 | inv, dst): ids of any width
-        ek, ed = edges
-        fwd_k, fwd_d = ek[0::2].contiguous(), ed[0::2].contiguous()
-        rev_k, rev_d = ek[1::2].contiguous(), ed[1::2].contiguous()
+        fwd_k, fwd_d = (pi << 11) | inv, pj.to(torch.int32)
+        rev_k, rev_d = (pj << 11) | inv, pi.to(torch.int32)
         if pairs.numel():
             rev_k, rev_d = be.group_by_owner(rev_k, 11, nql, rev_d)
         sizes = be.owner_sizes(rev_k, 11, nql, world)
@@ -231,8 +293,8 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
         rd_in = _exchange_var(sizes, rev_d.view(torch.int32), group)
         edges_local = (torch.cat([rk_in, fwd_k]), torch.cat([rd_in, fwd_d]))
     else:
-        fwd = edges[0::2].contiguous()
-        rev = edges[1::2].contiguous()
+        fwd = (pi << (ib + 11)) | (inv << ib) | pj
+        rev = (pj << (ib + 11)) | (inv << ib) | pi
         if pairs.numel():
             rev = be.group_by_owner(rev, ib + 11, nql)[0]
         rev_in = _exchange_var(be.owner_sizes(rev, ib + 11, nql, world), rev, group)

@@ -32,11 +32,13 @@ def main():
     perms = ops.legacy_permutations(P, D, seed=42)
     table = ops.perm_table(perms, dev)
     off, rows = qrlsh.synth_csr(nq, D, seed=0, q0=rank * nql, nq_local=nql, device=dev)
-    res = qdist.query_similarities_sharded(off, rows, table, b, K, nq, exchange=mode)
+    sig_mode = sys.argv[8] if len(sys.argv) > 8 else "auto"
+    res = qdist.query_similarities_sharded(off, rows, table, b, K, nq, exchange=mode, sig_exchange=sig_mode)
     torch.cuda.synchronize()
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), pairs=res.pairs.cpu().numpy(), milli=res.milli.cpu().numpy(),
              src=res.src.cpu().numpy(), dst=res.dst.cpu().numpy(), val=res.val.cpu().numpy(),
-             emitted=res.stats["emitted_pairs"])
+             emitted=res.stats["emitted_pairs"], sig_exchange=res.stats["sig_exchange"],
+             fetched=res.stats.get("remote_rows_fetched", -1))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -75,29 +75,14 @@ class OracleBackend:
         d = (w >> np.uint64(lo)) & np.uint64((1 << (hi - lo)) - 1)
         return _t(w[np.argsort(d, kind="stable")].view(np.int64))
 
-    def verify(self, sig_all, b, pairs):
+    def verify_flags(self, sig_rows, b, pairs):
+        """1 where the pair (two row indices of sig_rows) really shares a non-empty band"""
         p = pairs.numpy().view(np.uint64)
-        truth = O.candidates_from_sig(sig_all.numpy(), b)
-        return _t(p[np.isin(p, truth)].view(np.int64))
+        truth = O.candidates_from_sig(np.ascontiguousarray(sig_rows.numpy()), b)
+        return _t(np.isin(p, truth).astype(np.uint8))
 
-    def score(self, sig_all, norm_all, pairs, id_bits, wide=False):
-        p = pairs.numpy().view(np.uint64)
-        milli = O.score_pairs(sig_all.numpy(), p, mode=1)
-        i = p >> np.uint64(32)
-        j = p & np.uint64(0xFFFFFFFF)
-        inv = (1000 - milli).astype(np.uint64)
-        e = np.empty(2 * len(p), dtype=np.uint64)
-        if wide:
-            e[0::2] = (i << np.uint64(11)) | inv
-            e[1::2] = (j << np.uint64(11)) | inv
-            d = np.empty(2 * len(p), dtype=np.int32)
-            d[0::2] = j.astype(np.int32)
-            d[1::2] = i.astype(np.int32)
-            return _t(milli), (_t(e.view(np.int64)), _t(d))
-        sh = np.uint64(id_bits + 11)
-        e[0::2] = (i << sh) | (inv << np.uint64(id_bits)) | j
-        e[1::2] = (j << sh) | (inv << np.uint64(id_bits)) | i
-        return _t(milli), _t(e.view(np.int64))
+    def score_only(self, sig_rows, norm_rows, pairs):
+        return _t(O.score_pairs(np.ascontiguousarray(sig_rows.numpy()), pairs.numpy().view(np.uint64), mode=1))
 
     def owner_sizes(self, words, lo, shard, world):
         w = words.numpy().view(np.uint64)
@@ -141,7 +126,9 @@ class OracleBackend:
 
 def main():
     out_dir, nq, D, P, b, mode = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
-    wide = len(sys.argv) > 7 and sys.argv[7] == "wide"
+    extra = sys.argv[7:]
+    wide = "wide" in extra
+    sig_mode = ([e[4:] for e in extra if e.startswith("sig=")] or ["auto"])[0]
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     nql = nq // world
@@ -149,10 +136,11 @@ def main():
     perms = O.legacy_permutations(42, P, D)
     off, rows = O.synth_csr(nq, D, seed=3, cluster=4, mean=6.0, q0=rank * nql, nq_local=nql)
     res = qdist.query_similarities_sharded(_t(off), _t(rows), OracleTable(perms), b, K, nq, exchange=mode,
-                                           backend=OracleBackend(), wide_ids=wide or None)
+                                           backend=OracleBackend(), wide_ids=wide or None, sig_exchange=sig_mode)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), sig=res.sig.numpy(), pairs=res.pairs.numpy(),
              milli=res.milli.numpy(), src=res.src.numpy(), dst=res.dst.numpy(), val=res.val.numpy(),
-             emitted=res.stats["emitted_pairs"])
+             emitted=res.stats["emitted_pairs"], sig_exchange=res.stats["sig_exchange"],
+             fetched=res.stats.get("remote_rows_fetched", -1))
     dist.barrier()
     dist.destroy_process_group()
 

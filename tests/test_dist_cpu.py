@@ -25,14 +25,21 @@ def _run(tmp_path, world, nq, D, P, b, mode, port, extra=()):
     return [np.load(os.path.join(tmp_path, "rank%d.npz" % r)) for r in range(world)]
 
 
-@pytest.mark.parametrize("world,mode,b,extra", [(2, "all_to_all", 8, ()), (2, "all_gather", 8, ()),
-                                               (3, "all_to_all", 8, ()), (2, "all_to_all", 4, ("wide",))])
+@pytest.mark.parametrize("world,mode,b,extra", [(2, "all_to_all", 8, ()), (2, "all_gather", 8, ("sig=fetch",)),
+                                               (3, "all_to_all", 8, ("sig=fetch",)),
+                                               (3, "all_to_all", 8, ("sig=all_gather",)),
+                                               (2, "all_to_all", 4, ("wide", "sig=fetch")),
+                                               (2, "all_to_all", 4, ("wide", "sig=all_gather"))])
 def test_sharded_equals_single_process(tmp_path, world, mode, b, extra):
     # b = 4 with P = 32 is a wide band (r = 8: hashed bucket ids + verification); "wide" forces the
     # key + payload edge format used when two ids + 11 score bits do not fit 64 bits
     nq, D, P = 600, 512, 32
-    outs = _run(tmp_path, world, nq, D, P, b, mode, 29531 + world + (0 if mode == "all_to_all" else 7) + len(extra) * 11,
-                extra)
+    port = 29531 + world + (0 if mode == "all_to_all" else 7) + len(extra) * 11 + sum(map(len, extra))
+    outs = _run(tmp_path, world, nq, D, P, b, mode, port, extra)
+    for o in outs:     # the signature exchange that was asked for is the one that ran ("auto": either)
+        want = [e[4:] for e in extra if e.startswith("sig=")]
+        assert not want or str(o["sig_exchange"]) == want[0]
+        assert (str(o["sig_exchange"]) == "fetch") == (int(o["fetched"]) >= 0)
     K = O.max_candidates(nq)
     off, rows = O.synth_csr(nq, D, seed=3, cluster=4, mean=6.0)
     ref = O.query_similarities(off, rows, D, P, b, K, 42)

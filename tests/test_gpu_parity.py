@@ -421,7 +421,7 @@ def test_full_size_config2_properties_and_oracle():
 
 
 # ---------------------------------------------------------------------------- sharded driver
-def _run_dist_gpu(tmp_path, world, nq, D, P, b, mode, backend, port):
+def _run_dist_gpu(tmp_path, world, nq, D, P, b, mode, backend, port, sig_mode="auto"):
     import subprocess
     import sys as _sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -430,17 +430,24 @@ def _run_dist_gpu(tmp_path, world, nq, D, P, b, mode, backend, port):
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     cmd = [_sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "tests", "dist_gpu_worker.py"),
-           str(tmp_path), str(nq), str(D), str(P), str(b), mode, backend]
+           str(tmp_path), str(nq), str(D), str(P), str(b), mode, backend, sig_mode]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     return [np.load(os.path.join(tmp_path, "rank%d.npz" % r)) for r in range(world)]
 
 
-@pytest.mark.parametrize("world,mode,backend", [(1, "all_to_all", "nccl"), (2, "all_to_all", "gloo"),
-                                                (4, "all_gather", "gloo")])
-def test_sharded_driver_on_gpu_equals_single_gpu(tmp_path, world, mode, backend):
+@pytest.mark.parametrize("world,mode,backend,sig_mode", [(1, "all_to_all", "nccl", "auto"),
+                                                         (2, "all_to_all", "gloo", "auto"),
+                                                         (4, "all_gather", "gloo", "fetch"),
+                                                         (2, "all_to_all", "gloo", "all_gather")])
+def test_sharded_driver_on_gpu_equals_single_gpu(tmp_path, world, mode, backend, sig_mode):
     nq, D, P, b = 40000, 32768, 128, 32
-    outs = _run_dist_gpu(tmp_path, world, nq, D, P, b, mode, backend, 29571 + world)
+    outs = _run_dist_gpu(tmp_path, world, nq, D, P, b, mode, backend, 29571 + world + len(sig_mode), sig_mode)
+    for o in outs:
+        if sig_mode != "auto":
+            assert str(o["sig_exchange"]) == sig_mode
+        if world > 1 and str(o["sig_exchange"]) == "fetch":
+            assert 0 <= int(o["fetched"]) <= (world - 1) * (nq // world)   # only rows of the other shards, each once
     K = pipeline.max_candidates(nq)
     off, rows = qrlsh.synth_csr(nq, D, seed=0, device=DEV)
     res = pipeline.query_similarities(off, rows, ops.perm_table(ops.legacy_permutations(P, D, seed=42), DEV), b, K)

@@ -19,7 +19,7 @@ class B(qd.HipBackend):
     def emit_pairs(self,*a): T("pre-emit"); r=super().emit_pairs(*a); T("emit"); return r
     def sort_words(self,*a): r=super().sort_words(*a); T("sort_words"); return r
     def sort_unique(self,*a): r=super().sort_unique(*a); T("sort_unique"); return r
-    def score(self,*a): T("pre-score"); r=super().score(*a); T("score"); return r
+    def score_only(self,*a): T("pre-score"); r=super().score_only(*a); T("score"); return r
     def topk(self,*a): T("pre-topk"); r=super().topk(*a); T("topk"); return r
 for it in range(3):
     marks.clear()
