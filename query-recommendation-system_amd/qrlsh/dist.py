@@ -18,8 +18,8 @@ Rank g owns the contiguous query range [g*nql, (g+1)*nql) and bands {k : k // ce
                  volume at 8 ranks on the bench workload, most of it at 2;
        "all_gather": every rank receives every row ((W-1)/W * nq_total * 2P bytes per rank) on a
                  second communicator, asynchronously, beside steps 4-5.
-     "auto" (default) fetches unless the distinct remote rows of some rank exceed half of what the
-     all-gather would bring it.
+     "auto" (default): all_gather below 4 ranks (one or two peers: the volumes are close and the
+     gather hides behind steps 4-5), fetch from 4 ranks on (p rows against 3 - 7 shards).
   4. per owned band: bucket partition + pair emission over ALL queries; sorted by i only.
   5. pairs go to the owner of their smaller query id (variable-size all-to-all); the owner
      sorts + uniques what it received -> its share of the global candidate set.
@@ -229,6 +229,8 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
         na = torch.empty((nq_total,), dtype=torch.int64, device=dev)
         return sa, na, _all_gather(sa, sig, bg, async_op=True), _all_gather(na, norm2, bg, async_op=True)
 
+    if sig_exchange == "auto":
+        sig_exchange = "all_gather" if world in (2, 3) else "fetch"
     gathered = start_gather() if sig_exchange == "all_gather" else None
 
     # 4. candidates of the owned bands over all queries
@@ -255,13 +257,6 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
         # which rows of other ranks do my pairs touch?  (i is local by construction)
         remote = (pj < q0) | (pj >= q0 + nql)
         need = torch.unique(pj[remote])                     # ascending
-        if sig_exchange == "auto" and world > 1:
-            most = torch.tensor([need.numel()], dtype=torch.int64, device=dev)
-            if _staged(most, group):
-                most = most.cpu()
-            dist.all_reduce(most, op=dist.ReduceOp.MAX, group=group)
-            if int(most.item()) * 2 > (world - 1) * nql:    # not a sliver: the plain gather moves less
-                gathered = start_gather()
     stats["sig_exchange"] = "all_gather" if gathered is not None else "fetch"
     if gathered is not None:
         sig_rows, norm_rows, h_sig, h_nrm = gathered
