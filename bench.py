@@ -61,7 +61,8 @@ def algorithmic_bytes_per_step(w):
     sb = w["sig_bytes"]
     rec = b * w["nq_sorted"]                      # (band, query) records this rank buckets
     ib = max(1, (w["nq_total"] - 1).bit_length())
-    pair_passes = -(-ib // 8)                     # pairs are grouped by i only; rows are finished in LDS
+    g = ib % 8 if (ib > 8 and 0 < ib % 8 <= 4) else 0   # ops.row_group_bits: low bits of i the grouping sort skips
+    pair_passes = -(-(ib - g) // 8)               # pairs are grouped by i >> g only; rows are finished in LDS
     edge_passes = -(-(ib + 11) // 8)
     out = {
         # CSR in (4 B/row id + 8 B offset); signature row, fused band keys and norm out
