@@ -227,33 +227,31 @@ __global__ __launch_bounds__(256) void minhash_group_kernel(const int64_t *__res
     const int64_t qi = qw0 + lane;
     if (lane <= MH_QPW) offs = offsets[qi < nq ? qi : nq];
   }
-  auto batch_lo = [&](int batch, int &n) -> int64_t {
-    const int ql = batch * G + g;
-    const int64_t lo = __shfl(offs, ql, WAVE), hi = __shfl(offs, ql + 1, WAVE);
-    n = (qw0 + ql < nq) ? (int)(hi - lo) : 0;
+  auto batch_lo = [&](int batch, int &n, int &qlw) -> int64_t {
+    qlw = batch * G + g;  // the wave-local query this group works on in this batch
+    const int64_t lo = __shfl(offs, qlw, WAVE), hi = __shfl(offs, qlw + 1, WAVE);
+    n = (qw0 + qlw < nq) ? (int)(hi - lo) : 0;
     return lo;
   };
-  int n_cur;
-  int64_t lo_cur = batch_lo(0, n_cur);
+  int n_cur, qlw_cur;
+  int64_t lo_cur = batch_lo(0, n_cur, qlw_cur);
   int my_cur = (lig < n_cur) ? rows[lo_cur + lig] : 0;
 
 #pragma unroll 1
   for (int batch = 0; batch < MH_QPW / G; ++batch) {
-    const int ql = wave * MH_QPW + batch * G + g;  // query index inside the workgroup
+    const int ql = wave * MH_QPW + qlw_cur;  // query index inside the workgroup
     const int64_t q = q0 + ql;
     // prefetch the next batch's first LPR row ids
-    int n_nxt = 0, my_nxt = 0;
+    int n_nxt = 0, my_nxt = 0, qlw_nxt = 0;
     int64_t lo_nxt = 0;
     if (batch + 1 < MH_QPW / G) {
-      lo_nxt = batch_lo(batch + 1, n_nxt);
+      lo_nxt = batch_lo(batch + 1, n_nxt, qlw_nxt);
       if (lig < n_nxt) my_nxt = rows[lo_nxt + lig];
     }
     VecT acc = TabVec<TabT>::init();
     int my = my_cur;
-    // min is idempotent: slots past the end of a (shorter) answer set re-read the query's first
-    // row instead of being predicated off, so the MH_CH gathers of a step are independent
-    // loads in flight together rather than MH_CH exec-masked load -> wait -> min round trips.
-    const int d_first = group_bcast<LPR>(my, 0, g);
+    // the MH_CH gathers of a step sit in their own exec regions with the min after all of them, so
+    // they are independent loads in flight together, not MH_CH load -> wait -> min round trips
     for (int base = 0; __any(base < n_cur); base += LPR) {
       const int my_after = (base + LPR + lig < n_cur) ? rows[lo_cur + base + LPR + lig] : 0;
 #pragma unroll
@@ -263,9 +261,10 @@ __global__ __launch_bounds__(256) void minhash_group_kernel(const int64_t *__res
 #pragma unroll
         for (int j = 0; j < MH_CH; ++j) {
           const int ds = group_bcast<LPR>(my, sub + j, g);
-          const int d = (base + sub + j < n_cur) ? ds : d_first;
           // 32-bit byte offset from a uniform base (table < 4 GiB, d < 2^24: checked by the host)
-          v[j] = *reinterpret_cast<const VecT *>(tbytes + (__umul24((uint32_t)d, row_bytes) + col_bytes));
+          v[j] = TabVec<TabT>::init();
+          if (base + sub + j < n_cur)
+            v[j] = *reinterpret_cast<const VecT *>(tbytes + (__umul24((uint32_t)ds, row_bytes) + col_bytes));
         }
 #pragma unroll
         for (int j = 0; j < MH_CH; ++j) acc = __builtin_elementwise_min(acc, v[j]);
@@ -287,6 +286,7 @@ __global__ __launch_bounds__(256) void minhash_group_kernel(const int64_t *__res
     n_cur = n_nxt;
     lo_cur = lo_nxt;
     my_cur = my_nxt;
+    qlw_cur = qlw_nxt;
   }
 
   if (keys) {

@@ -1,30 +1,64 @@
-import os, sys, time
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "query-recommendation-system_amd"))
-import torch, torch.distributed as dist
-os.environ.setdefault("MASTER_ADDR","127.0.0.1"); os.environ.setdefault("MASTER_PORT","29577")
-torch.cuda.set_device(0); dev=torch.device("cuda",0)
+#!/usr/bin/env python3
+"""Where the sharded driver's wall time goes at world = 1 (development tool): wraps the backend
+methods and the collectives with synchronised timestamps.  usage: python tools/dist_timing.py [nq]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "query-recommendation-system_amd")):
+    sys.path.insert(0, p)
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29577")
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
 dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
-import qrlsh
-from qrlsh import ops, pipeline, dist as qd
-nq=1_000_000; P=128; b=32; D=32768; K=34
-off,rows=qrlsh.synth_csr(nq,D,seed=0,device=dev)
-table=ops.perm_table(ops.legacy_permutations(P,D,seed=42),dev)
-# monkeypatch timing points
-marks=[]
-orig_a2a=qd._all_to_all; orig_ag=qd._all_gather; orig_ex=qd._exchange_var
-def T(name):
-    torch.cuda.synchronize(); marks.append((name,time.perf_counter()))
-class B(qd.HipBackend):
-    def minhash(self,*a): T("start"); r=super().minhash(*a); T("minhash"); return r
-    def emit_pairs(self,*a): T("pre-emit"); r=super().emit_pairs(*a); T("emit"); return r
-    def sort_words(self,*a): r=super().sort_words(*a); T("sort_words"); return r
-    def sort_unique(self,*a): r=super().sort_unique(*a); T("sort_unique"); return r
-    def score_only(self,*a): T("pre-score"); r=super().score_only(*a); T("score"); return r
-    def topk(self,*a): T("pre-topk"); r=super().topk(*a); T("topk"); return r
-for it in range(3):
-    marks.clear()
-    res=qd.query_similarities_sharded(off,rows,table,b,K,nq,backend=B())
-    T("end")
-for (n0,t0),(n1,t1) in zip(marks[:-1],marks[1:]): print("%-12s -> %-12s %.3f ms"%(n0,n1,(t1-t0)*1e3))
-print("total %.3f ms"%((marks[-1][1]-marks[0][1])*1e3))
+import qrlsh  # noqa: E402
+from qrlsh import ops, dist as qd  # noqa: E402
+
+nq = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+P, b, D, K = 128, 32, 32768, 34
+off, rows = qrlsh.synth_csr(nq, D, seed=0, device=dev)
+table = ops.perm_table(ops.legacy_permutations(P, D, seed=42), dev)
+acc = {}
+last = [0.0]
+
+
+def mark(name):
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    acc[name] = acc.get(name, 0.0) + (t - last[0])
+    last[0] = t
+
+
+def wrap(obj, name, label=None):
+    f = getattr(obj, name)
+
+    def g(*a, **k):
+        mark("host/other")
+        r = f(*a, **k)
+        mark(label or name)
+        return r
+    setattr(obj, name, g)
+
+
+be = qd.HipBackend()
+for m in ("minhash", "emit_pairs", "sort_unique", "group_by_owner", "owner_sizes", "score_only", "topk"):
+    wrap(be, m)
+wrap(qd, "_all_to_all", "collective:all_to_all")
+wrap(qd, "_all_gather", "collective:all_gather")
+mode = sys.argv[2] if len(sys.argv) > 2 else "auto"
+for it in range(4):
+    acc.clear()
+    torch.cuda.synchronize()
+    t0 = last[0] = time.perf_counter()
+    res = qd.query_similarities_sharded(off, rows, table, b, K, nq, backend=be, sig_exchange=mode)
+    mark("host/other")
+    total = time.perf_counter() - t0
+for k, v in sorted(acc.items(), key=lambda kv: -kv[1]):
+    print("%-26s %8.3f ms" % (k, v * 1e3))
+print("total (with the syncs this tool adds) %.3f ms; sig_exchange=%s" % (total * 1e3, res.stats["sig_exchange"]))
 dist.destroy_process_group()
