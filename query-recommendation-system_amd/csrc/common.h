@@ -111,6 +111,56 @@ __device__ static inline uint64_t block_excl_scan_u64_256(uint64_t v, uint64_t *
   return base + inc - v;
 }
 
+// ---- large arrays: three small launches (chunk scans, scan of the chunk totals, add) ------------
+constexpr int SCANL_THREADS = 1024;
+constexpr int SCANL_PER = 16;
+constexpr int SCANL_CHUNK = SCANL_THREADS * SCANL_PER;  // 16384 elements per workgroup
+
+// in-place exclusive scan of every chunk; chunk total -> sums[chunk]
+static __global__ __launch_bounds__(SCANL_THREADS) void scan_chunks_kernel(uint64_t *__restrict__ a, int64_t m,
+                                                                           uint64_t *__restrict__ sums) {
+  __shared__ uint64_t wsum[SCANL_THREADS / 64];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int64_t lo = (int64_t)blockIdx.x * SCANL_CHUNK + (int64_t)t * SCANL_PER;
+  uint64_t held[SCANL_PER], s = 0;
+#pragma unroll
+  for (int k = 0; k < SCANL_PER; ++k) held[k] = lo + k < m ? a[lo + k] : 0;
+#pragma unroll
+  for (int k = 0; k < SCANL_PER; ++k) s += held[k];
+  uint64_t inc = s;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint64_t o = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += o;
+  }
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  uint64_t run = inc - s, tot = 0;
+#pragma unroll
+  for (int k = 0; k < SCANL_THREADS / 64; ++k) {
+    if (k < w) run += wsum[k];
+    tot += wsum[k];
+  }
+#pragma unroll
+  for (int k = 0; k < SCANL_PER; ++k)
+    if (lo + k < m) {
+      a[lo + k] = run;
+      run += held[k];
+    }
+  if (t == 0) sums[blockIdx.x] = tot;
+}
+
+static __global__ __launch_bounds__(SCANL_THREADS) void scan_add_kernel(uint64_t *__restrict__ a, int64_t m,
+                                                                        const uint64_t *__restrict__ sums) {
+  const uint64_t add = sums[blockIdx.x];
+  const int64_t lo = (int64_t)blockIdx.x * SCANL_CHUNK;
+#pragma unroll
+  for (int k = 0; k < SCANL_PER; ++k) {
+    const int64_t i = lo + (int64_t)k * SCANL_THREADS + threadIdx.x;
+    if (i < m) a[i] += add;
+  }
+}
+
 // in-place exclusive scan of m uint64 (one workgroup); the grand total goes to *total_out
 static __global__ __launch_bounds__(1024) void scan_u64_kernel(uint64_t *__restrict__ a, int64_t m,
                                                         uint64_t *__restrict__ total_out) {
@@ -154,5 +204,19 @@ static __global__ __launch_bounds__(1024) void scan_u64_kernel(uint64_t *__restr
     }
   }
   if (t == 0) *total_out = tot;
+}
+
+// exclusive scan of m uint64 in place, total to *total_out.  `sums` = scratch of
+// ceil(m / SCANL_CHUNK) words, used (with two more launches) only when the array is large.
+static inline void qr_scan_u64(uint64_t *a, int64_t m, uint64_t *total_out, uint64_t *sums, hipStream_t st) {
+  if (m <= 2 * SCANL_CHUNK || sums == nullptr) {
+    QR_LAUNCH("scan_blocks", scan_u64_kernel, dim3(1), dim3(1024), 0, st, a, m, total_out);
+    return;
+  }
+  const int64_t nch = (m + SCANL_CHUNK - 1) / SCANL_CHUNK;
+  QR_LAUNCH("scan_blocks", scan_chunks_kernel, dim3((unsigned)nch), dim3(SCANL_THREADS), 0, st, a, m, sums);
+  QR_LAUNCH("scan_blocks", scan_u64_kernel, dim3(1), dim3(1024), 0, st, sums, nch, total_out);
+  QR_LAUNCH("scan_blocks", scan_add_kernel, dim3((unsigned)nch), dim3(SCANL_THREADS), 0, st, a, m,
+            (const uint64_t *)sums);
 }
 

@@ -271,9 +271,11 @@ QRLSH_EXPORT int qrlsh_pairs_fill(const uint64_t *sorted_keys, const uint32_t *s
   return QRLSH_OK;
 }
 
+// workspace: per-tile counts [nblk] | chunk totals of the large-array scan
 QRLSH_EXPORT size_t qrlsh_compact_workspace_bytes(int64_t n) {
   if (n <= 0) return 16;
-  return (size_t)ceil_div64(n, CMP_TILE) * sizeof(uint64_t);
+  const int64_t nblk = ceil_div64(n, CMP_TILE);
+  return (size_t)(nblk + ceil_div64(nblk, SCANL_CHUNK) + 1) * sizeof(uint64_t);
 }
 
 template <int PRED>
@@ -296,7 +298,7 @@ static int compact_count(const uint64_t *a, int64_t n, int K, int sh, void *work
   const int64_t nblk = ceil_div64(n, CMP_TILE);
   uint64_t *blk = static_cast<uint64_t *>(workspace);
   QR_LAUNCH(PRED == PRED_UNIQUE ? "unique_count" : "topk_count", (compact_count_kernel<PRED>), dim3((unsigned)nblk), dim3(CMP_THREADS), 0, st, a, n, K, sh, blk);
-  QR_LAUNCH("scan_blocks", scan_u64_kernel, dim3(1), dim3(1024), 0, st, blk, nblk, total_out);
+  qr_scan_u64(blk, nblk, total_out, blk + nblk, st);
   QR_LAUNCH_CHECK(name);
   return QRLSH_OK;
 }
@@ -640,10 +642,10 @@ __global__ __launch_bounds__(RD_THREADS) void row_unique_gather_kernel(const uin
   }
 }
 
-// workspace: counts[2 nblk + 1] | starts[2 nblk] | longlist[nblk] | nlong
+// workspace: counts[2 nblk + 1] | starts[2 nblk] | longlist[nblk] | nlong | chunk totals of the scan
 QRLSH_EXPORT size_t qrlsh_row_unique_workspace_bytes(int64_t n) {
   const int64_t nblk = n > 0 ? ceil_div64(n, RD_C) : 0;
-  return (size_t)(5 * nblk + 2) * sizeof(uint64_t);
+  return (size_t)(5 * nblk + 2 + ceil_div64(2 * nblk + 1, SCANL_CHUNK) + 1) * sizeof(uint64_t);
 }
 
 QRLSH_EXPORT int qrlsh_row_unique_count(const uint64_t *grouped, int64_t n, int32_t group_bits, int32_t id_bits,
@@ -679,7 +681,7 @@ QRLSH_EXPORT int qrlsh_row_unique_count(const uint64_t *grouped, int64_t n, int3
   QR_LAUNCH("row_unique_long", row_unique_long_kernel, dim3((unsigned)(nblk < RL_GRID ? nblk : RL_GRID)),
             dim3(RL_THREADS), 0, st, grouped, n, tmp, counts, (const uint64_t *)starts, (const uint64_t *)longlist,
             (const unsigned long long *)nlong, total_overflow_out + 1, group_bits, id_bits);
-  QR_LAUNCH("scan_blocks", scan_u64_kernel, dim3(1), dim3(1024), 0, st, counts, 2 * nblk + 1, total_overflow_out);
+  qr_scan_u64(counts, 2 * nblk + 1, total_overflow_out, nlong + 1, st);
   QR_LAUNCH_CHECK("qrlsh_row_unique_count");
   return QRLSH_OK;
 }

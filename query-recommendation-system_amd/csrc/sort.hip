@@ -118,17 +118,21 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const uint64_t 
 // One workgroup per (digit, batch) row of ghist: exclusive scan of the row's ntiles tile
 // counts in place, and the row total to rtot[batch][digit].  The scatter kernel turns the
 // 256 row totals into digit bases itself, so a pass needs no single-workgroup scan.
-__global__ __launch_bounds__(256) void sort_rowscan_kernel(uint32_t *__restrict__ ghist, int ntiles,
-                                                           uint32_t *__restrict__ rtot) {
-  __shared__ uint32_t wsum[4];
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void sort_rowscan_kernel(uint32_t *__restrict__ ghist, int ntiles,
+                                                               uint32_t *__restrict__ rtot) {
+  constexpr int NW = THREADS / WAVE;
+  __shared__ uint32_t wsum[NW];
   const int d = blockIdx.x, batch = blockIdx.y;
   uint32_t *row = ghist + ((size_t)batch * RADIX + d) * ntiles;
   const int t = threadIdx.x, lane = t & (WAVE - 1), w = t >> 6;
-  constexpr int ROW_REG = 32;  // rows of up to 8192 tiles (33 M keys per batch) are scanned from registers
-  const int per = (ntiles + 255) / 256;
+  // rows are scanned from registers: 256 threads x 32 for up to 8192 tiles (33 M keys per batch),
+  // 1024 threads x 64 for up to 65536 tiles (268 M keys); longer rows take the chunked loop below
+  constexpr int ROW_REG = THREADS == 256 ? 32 : 64;
+  const int per = (ntiles + THREADS - 1) / THREADS;
   if (per <= ROW_REG) {
     // blocked layout: thread t owns `per` consecutive tiles; every load is issued before the first
-    // add, and the whole row needs one workgroup scan instead of one per 256 tiles
+    // add, and the whole row needs one workgroup scan instead of one per THREADS tiles
     const int lo = t * per;
     uint32_t held[ROW_REG], s = 0;
 #pragma unroll
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(256) void sort_rowscan_kernel(uint32_t *__restrict_
     __syncthreads();
     uint32_t run = inc - s, tot = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < NW; ++k) {
       const uint32_t x = wsum[k];
       if (k < w) run += x;
       tot += x;
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(256) void sort_rowscan_kernel(uint32_t *__restrict_
     return;
   }
   uint32_t carry = 0;
-  for (int base = 0; base < ntiles; base += 256) {
+  for (int base = 0; base < ntiles; base += THREADS) {
     const int i = base + t;
     const uint32_t v = i < ntiles ? row[i] : 0;
     uint32_t inc = v;
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(256) void sort_rowscan_kernel(uint32_t *__restrict_
     __syncthreads();
     uint32_t wbase = 0, tot = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < NW; ++k) {
       const uint32_t x = wsum[k];
       if (k < w) wbase += x;
       tot += x;
@@ -183,6 +187,14 @@ __global__ __launch_bounds__(256) void sort_rowscan_kernel(uint32_t *__restrict_
     __syncthreads();
   }
   if (t == 0) rtot[(size_t)batch * RADIX + d] = carry;
+}
+
+// one row-scan launch: 256-thread workgroups while a row fits their registers, 1024 above
+static void launch_rowscan(uint32_t *ghist, int ntiles, uint32_t *rtot, int nbatch, hipStream_t st) {
+  if (ntiles <= 256 * 32)
+    QR_LAUNCH("sort_rowscan", sort_rowscan_kernel<256>, dim3(RADIX, nbatch), dim3(256), 0, st, ghist, ntiles, rtot);
+  else
+    QR_LAUNCH("sort_rowscan", sort_rowscan_kernel<1024>, dim3(RADIX, nbatch), dim3(1024), 0, st, ghist, ntiles, rtot);
 }
 
 template <int MIX, bool HAS_VAL, bool IOTA, bool SPREAD = false>
@@ -629,7 +641,7 @@ static int sort_passes(uint64_t *ka, uint64_t *kb, uint32_t *va, uint32_t *vb, i
     uint64_t *kin = cur ? kb : ka, *kout = cur ? ka : kb;
     uint32_t *vin = cur ? vb : va, *vout = cur ? va : vb;
     QR_LAUNCH("sort_hist", (sort_hist_kernel<MIX>), grid, block, 0, st, kin, n, ntiles, shift, ghist, (uint64_t)0, fold);
-    QR_LAUNCH("sort_rowscan", sort_rowscan_kernel, dim3(RADIX, nbatch), dim3(256), 0, st, ghist, ntiles, rtot);
+    launch_rowscan(ghist, ntiles, rtot, nbatch, st);
     if (!has_val && (MIX == SM_PLAIN || MIX == SM_FOLD))
       QR_LAUNCH("sort_scatter_k", (sort_scatter_staged_kernel<MIX>), grid, block, 0, st, kin, kout, n, ntiles, shift,
                 ghist, rtot, fold);
@@ -972,7 +984,7 @@ static void bucket_partition(const uint64_t *keys, uint64_t *part_keys, uint32_t
   if (T == 8) {
     QR_LAUNCH("sort_hist", (sort_hist_kernel<SM_MIX, true>), grid, block, 0, st, keys, nq, ntiles, 56, w.ghist, ek, 0,
               (uint32_t)RADIX - 1u, no_vals);
-    QR_LAUNCH("sort_rowscan", sort_rowscan_kernel, dim3(RADIX, b), dim3(256), 0, st, w.ghist, ntiles, w.rtot);
+    launch_rowscan(w.ghist, ntiles, w.rtot, b, st);
     if (staged)
       QR_LAUNCH("sort_scatter_kv", (part_scatter_staged_kernel<true>), grid, block, 0, st, keys, no_vals, part_keys,
                 part_ids, nq, ntiles, 56, w.ghist, w.rtot, ek, (uint32_t)RADIX - 1u);
@@ -984,7 +996,7 @@ static void bucket_partition(const uint64_t *keys, uint64_t *part_keys, uint32_t
     const uint32_t lowmask = (1u << (T - 8)) - 1u;
     QR_LAUNCH("sort_hist", (sort_hist_kernel<SM_MIX, true>), grid, block, 0, st, keys, nq, ntiles, 64 - T, w.ghist, ek, 0,
               lowmask, no_vals);
-    QR_LAUNCH("sort_rowscan", sort_rowscan_kernel, dim3(RADIX, b), dim3(256), 0, st, w.ghist, ntiles, w.rtot);
+    launch_rowscan(w.ghist, ntiles, w.rtot, b, st);
     if (staged)
       QR_LAUNCH("sort_scatter_kv", (part_scatter_staged_kernel<true>), grid, block, 0, st, keys, no_vals, tmp_keys,
                 tmp_ids, nq, ntiles, 64 - T, w.ghist, w.rtot, ek, lowmask);
@@ -993,7 +1005,7 @@ static void bucket_partition(const uint64_t *keys, uint64_t *part_keys, uint32_t
                 tmp_keys, tmp_ids, nq, ntiles, 64 - T, w.ghist, w.rtot, ek, 0, lowmask);
     QR_LAUNCH("sort_hist", (sort_hist_kernel<SM_MIX, true>), grid, block, 0, st, (const uint64_t *)tmp_keys, nq, ntiles,
               56, w.ghist, ek, 0, (uint32_t)RADIX - 1u, (const uint32_t *)tmp_ids);
-    QR_LAUNCH("sort_rowscan", sort_rowscan_kernel, dim3(RADIX, b), dim3(256), 0, st, w.ghist, ntiles, w.rtot);
+    launch_rowscan(w.ghist, ntiles, w.rtot, b, st);
     if (staged)
       QR_LAUNCH("sort_scatter_kv", (part_scatter_staged_kernel<false>), grid, block, 0, st, (const uint64_t *)tmp_keys,
                 (const uint32_t *)tmp_ids, part_keys, part_ids, nq, ntiles, 56, w.ghist, w.rtot, ek,

@@ -34,7 +34,7 @@ def test_library_host_only_entry_points():
     assert lib.qrlsh_version() >= 1
     assert lib.qrlsh_sort_workspace_bytes(4096 * 3, 2) == 2 * 256 * (3 + 1) * 4
     assert lib.qrlsh_pairs_workspace_bytes(1024 * 5 + 1, 3) == 3 * 6 * 8
-    assert lib.qrlsh_compact_workspace_bytes(2048 * 2) == 2 * 8
+    assert lib.qrlsh_compact_workspace_bytes(2048 * 2) == (2 + 1 + 1) * 8    # tile counts + scan chunk totals
     # the device mixer is a bijection: spot-check injectivity and the known splitmix64 vector
     vals = {lib.qrlsh_mix64_host(i) for i in range(10000)}
     assert len(vals) == 10000
