@@ -224,7 +224,7 @@ def main():
 
         cpu_baseline = None
         recall = None
-        if args.cpu_sample > 0:
+        if args.cpu_sample > 0 and world == 1:      # the CPU leg belongs to the one-GPU line only
             cpu_baseline, recall = cpu_leg(args.cpu_sample, D, P, b, dev, args.cpu_threads)
 
         out = {
