@@ -141,11 +141,13 @@ int qrlsh_bucket_pairs_fill(const uint64_t *part_keys, const uint32_t *part_ids,
  * `capacity` words of pairs_out are written; total_overflow_out[0] receives the exact number of pairs
  * whether or not they fitted (if it exceeds capacity: allocate that many and call again), [1] the same
  * oversized-part flag as qrlsh_bucket_pairs_count.  The pairs come out in no particular order.
- * part_keys / part_ids must hold qrlsh_bucket_part_words(nq, b, part_bits) words: with 256 parts the
- * partition is ONE kernel that gives every part a fixed region and reserves room in it with an atomic
- * per (tile, part) -- no histogram pass, no scan, no bounds search -- and those regions need more room
- * than the b * nq records themselves (a part outgrowing its region raises the same overflow flag). */
+ * part_keys / part_ids must hold qrlsh_bucket_part_words(nq, b, part_bits) words and, for part_bits > 8,
+ * tmp_keys / tmp_ids qrlsh_bucket_tmp_words(...): the partition is ONE kernel per 8 bits that gives every
+ * part a fixed region and reserves room in it with an atomic per (tile, part) -- no histogram pass, no
+ * scan, no bounds search -- and those regions need more room than the b * nq records themselves (a part
+ * outgrowing its region raises the same overflow flag). */
 size_t qrlsh_bucket_part_words(int64_t nq, int32_t b, int32_t part_bits);
+size_t qrlsh_bucket_tmp_words(int64_t nq, int32_t b, int32_t part_bits);
 int qrlsh_bucket_pairs_emit(const uint64_t *keys, uint64_t *part_keys, uint32_t *part_ids,
                             uint64_t *tmp_keys, uint32_t *tmp_ids, int64_t nq, int32_t b, int32_t r,
                             int32_t part_bits, void *workspace, size_t workspace_bytes,

@@ -519,36 +519,48 @@ __global__ __launch_bounds__(SORT_THREADS, 3) void part_scatter_staged_kernel(
 // row scan, no bounds search; the order of the records inside a part is whatever the atomics gave
 // (the finish does not care).  A part that would exceed `cap` raises the overflow word and its
 // records are dropped -- the caller then takes the general path.
+// LEVEL2 = false: the input is the band-major key matrix ([batch][n], ids = positions), 256 parts per band.
+// LEVEL2 = true : finer partitions (T > 8 bits) take a second step -- the input is the OUTPUT of a first
+// step, one batch per (band, coarse part): its in_counts[batch] records sit at batch * in_cap and are
+// dealt to nd = 2^(T-8) fine parts by the next bits of the same hash; ids come with the records.
+template <bool LEVEL2>
 __global__ __launch_bounds__(SORT_THREADS, 3) void part_scatter_atomic_kernel(
-    const uint64_t *__restrict__ keys_in, uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int64_t n,
-    int ntiles, int shift, uint32_t *__restrict__ cursors, uint32_t cap, uint32_t *__restrict__ overflow, uint64_t ek) {
+    const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint64_t *__restrict__ keys_out,
+    uint32_t *__restrict__ vals_out, int64_t n_in, int ntiles, int shift, uint32_t dmask,
+    uint32_t *__restrict__ cursors, uint32_t cap, uint32_t *__restrict__ overflow, uint64_t ek,
+    const uint32_t *__restrict__ in_counts, uint32_t in_cap) {
   __shared__ uint32_t cnt[SORT_THREADS / WAVE][RADIX];
   __shared__ uint32_t lsum[SORT_THREADS / WAVE];
   __shared__ uint32_t gdelta[RADIX];
   __shared__ uint8_t gok[RADIX];
   __shared__ uint64_t skey[SORT_TILE];
   __shared__ uint32_t sval[SORT_TILE];
-  const int tile = xcd_tile(blockIdx.x, ntiles), batch = blockIdx.y;
+  const int tile = LEVEL2 ? (int)blockIdx.x : xcd_tile(blockIdx.x, ntiles), batch = blockIdx.y;
   const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x >> 6;
+  const int64_t n = LEVEL2 ? (int64_t)min(in_counts[batch], in_cap) : n_in;
+  const int64_t tbase = (int64_t)tile * SORT_TILE;
+  if (tbase >= n) return;  // LEVEL2: the grid covers a full region, this one holds fewer records (uniform)
 #pragma unroll
   for (int i = 0; i < SORT_THREADS / WAVE; ++i) cnt[i][threadIdx.x] = 0;
   __syncthreads();
-  const size_t boff = (size_t)batch * n;
-  const int64_t tbase = (int64_t)tile * SORT_TILE;
+  const size_t boff = (size_t)batch * (LEVEL2 ? (size_t)in_cap : (size_t)n);
   const int64_t wbase = tbase + (int64_t)w * (WAVE * SORT_IPT);
+  const uint32_t nd = dmask + 1u;  // parts per batch
   uint64_t key[SORT_IPT];
+  uint32_t val[SORT_IPT];
   uint32_t dr[SORT_IPT];
   const uint64_t lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
   for (int k = 0; k < SORT_IPT; ++k) {
     const int64_t idx = wbase + (int64_t)k * WAVE + lane;
     key[k] = idx < n ? keys_in[boff + idx] : 0;
+    val[k] = LEVEL2 ? (idx < n ? vals_in[boff + idx] : 0u) : (uint32_t)idx;
   }
 #pragma unroll
   for (int k = 0; k < SORT_IPT; ++k) {
     const int64_t idx = wbase + (int64_t)k * WAVE + lane;
     const bool valid = idx < n;
-    const uint32_t d = part_digit<true>(key[k], idx, shift, ek, RADIX - 1);
+    const uint32_t d = part_digit<true>(key[k], (int64_t)val[k], shift, ek, dmask);
     uint64_t m = __ballot(valid);
 #pragma unroll
     for (int bit = 0; bit < 8; ++bit) {
@@ -571,7 +583,7 @@ __global__ __launch_bounds__(SORT_THREADS, 3) void part_scatter_atomic_kernel(
 #pragma unroll
     for (int i = 0; i < SORT_THREADS / WAVE; ++i) tc += cnt[i][d];
     // the reservation goes out first: its latency hides behind the scan below
-    const uint32_t gb = tc ? atomicAdd(&cursors[(size_t)batch * RADIX + d], tc) : 0u;
+    const uint32_t gb = tc ? atomicAdd(&cursors[(size_t)batch * nd + d], tc) : 0u;
     uint32_t linc = tc;
 #pragma unroll
     for (int k = 1; k < WAVE; k <<= 1) {
@@ -603,12 +615,12 @@ __global__ __launch_bounds__(SORT_THREADS, 3) void part_scatter_atomic_kernel(
     if (idx < n) {
       const uint32_t d = dr[k] >> 16, lp = cnt[w][d] + (dr[k] & 0xFFFFu);
       skey[lp] = key[k];
-      sval[lp] = (uint32_t)idx | d << 24;
+      sval[lp] = val[k] | d << 24;
     }
   }
   __syncthreads();
   const int ntile = (int)min((int64_t)SORT_TILE, n - tbase);
-  const size_t obase = (size_t)batch * RADIX * cap;
+  const size_t obase = (size_t)batch * nd * cap;
 #pragma unroll
   for (int k = 0; k < SORT_IPT; ++k) {
     const int p = k * SORT_THREADS + threadIdx.x;
@@ -1068,12 +1080,38 @@ static uint32_t part_region(int64_t nq) {
   return (uint32_t)(c < FIN_CAP ? c : FIN_CAP);
 }
 
-// words part_keys / part_ids must hold for qrlsh_bucket_pairs_emit
+// finer partitions (T > 8) go through two such kernels: 256 coarse regions per band, then 2^(T-8) fine
+// regions inside each (2 x mean + 128, at most the LDS image)
+static uint32_t coarse_region(int64_t nq) {
+  // equal keys share a region: beside the hash-uniform spread there must be room for popular keys (one
+  // with more copies than the LDS image overflows the fine step anyway)
+  const double a = (double)nq / RADIX;
+  const double slack = a >= 4096.0 ? 0.25 * a + 8192.0 : 6.0 * sqrt(a) + 2.0 * a + 64.0;
+  return (uint32_t)(((int64_t)(a + slack) + 63) / 64 * 64);
+}
+static uint32_t fine_region(int64_t nq, int T) {
+  // real sizes (mean >= 1024 records per part): the whole LDS image, so that a popular key with a few
+  // thousand copies still fits its part, as in the sort-based partition; tiny inputs: 2 x mean + 128
+  if ((nq >> T) >= 1024) return FIN_CAP;
+  const int64_t c = ((nq >> T) * 2 + 128 + 63) / 64 * 64;
+  return (uint32_t)(c < FIN_CAP ? c : FIN_CAP);
+}
+static bool one_kernel_partition(int64_t nq, int part_bits) { return nq <= (1ll << 24) && part_bits >= 8; }
+
+// words part_keys / part_ids (and, for part_bits > 8, tmp_keys / tmp_ids) must hold for qrlsh_bucket_pairs_emit
 QRLSH_EXPORT size_t qrlsh_bucket_part_words(int64_t nq, int32_t b, int32_t part_bits) {
   if (nq <= 0 || b <= 0) return 0;
   const size_t plain = (size_t)b * nq;
-  if (part_bits != 8 || nq > (1ll << 24)) return plain;
-  const size_t regions = (size_t)b * RADIX * part_region(nq);
+  if (!one_kernel_partition(nq, part_bits)) return plain;
+  const size_t regions = part_bits == 8 ? (size_t)b * RADIX * part_region(nq)
+                                        : ((size_t)b << part_bits) * fine_region(nq, part_bits);
+  return regions > plain ? regions : plain;
+}
+QRLSH_EXPORT size_t qrlsh_bucket_tmp_words(int64_t nq, int32_t b, int32_t part_bits) {
+  if (nq <= 0 || b <= 0 || part_bits <= 8) return 0;
+  const size_t plain = (size_t)b * nq;
+  if (!one_kernel_partition(nq, part_bits)) return plain;
+  const size_t regions = (size_t)b * RADIX * coarse_region(nq);
   return regions > plain ? regions : plain;
 }
 
@@ -1102,13 +1140,38 @@ QRLSH_EXPORT int qrlsh_bucket_pairs_emit(const uint64_t *keys, uint64_t *part_ke
       return QRLSH_EHIP;
     }
     const int ntiles = (int)ceil_div64(nq, SORT_TILE);
-    QR_LAUNCH("part_scatter", part_scatter_atomic_kernel, dim3(ntiles, b), dim3(SORT_THREADS), 0, st, keys, part_keys,
-              part_ids, nq, ntiles, 56, cursors, cap, reinterpret_cast<uint32_t *>(total_overflow_out + 1),
-              qr_empty_key(r));
+    QR_LAUNCH("part_scatter", part_scatter_atomic_kernel<false>, dim3(ntiles, b), dim3(SORT_THREADS), 0, st, keys,
+              (const uint32_t *)nullptr, part_keys, part_ids, nq, ntiles, 56, (uint32_t)RADIX - 1u, cursors, cap,
+              reinterpret_cast<uint32_t *>(total_overflow_out + 1), qr_empty_key(r), (const uint32_t *)nullptr, 0u);
     QR_LAUNCH("bucket_emit", (bucket_finish_kernel<FIN_EMIT>), dim3(nparts, b), dim3(FIN_THREADS), 0, st,
               (const uint64_t *)part_keys, (const uint32_t *)part_ids, nq, (const uint32_t *)nullptr, nparts,
               qr_empty_key(r), total_overflow_out, reinterpret_cast<uint32_t *>(total_overflow_out + 1), pairs_out,
               capacity, (const uint32_t *)cursors, cap);
+    QR_LAUNCH_CHECK("qrlsh_bucket_pairs_emit");
+    return QRLSH_OK;
+  }
+  if (one_kernel_partition(nq, part_bits)) {
+    // two steps of the same kernel: 256 coarse regions per band into the tmp buffers, then every coarse
+    // region into its 2^(T-8) fine regions; cursors of step 1 borrow the histogram area, step 2's `starts`
+    const int T = part_bits;
+    const uint32_t cap1 = coarse_region(nq), cap2 = fine_region(nq, T), lowmask = (1u << (T - 8)) - 1u;
+    uint32_t *cur1 = w.ghist, *cur2 = w.starts;
+    if (hipMemsetAsync(cur1, 0, (size_t)b * RADIX * sizeof(uint32_t), st) != hipSuccess ||
+        hipMemsetAsync(cur2, 0, ((size_t)b << T) * sizeof(uint32_t), st) != hipSuccess) {
+      qrlsh_set_error("qrlsh_bucket_pairs_emit: hipMemsetAsync failed");
+      return QRLSH_EHIP;
+    }
+    uint32_t *ovf = reinterpret_cast<uint32_t *>(total_overflow_out + 1);
+    const int ntiles = (int)ceil_div64(nq, SORT_TILE);
+    QR_LAUNCH("part_scatter", part_scatter_atomic_kernel<false>, dim3(ntiles, b), dim3(SORT_THREADS), 0, st, keys,
+              (const uint32_t *)nullptr, tmp_keys, tmp_ids, nq, ntiles, 56, (uint32_t)RADIX - 1u, cur1, cap1, ovf,
+              qr_empty_key(r), (const uint32_t *)nullptr, 0u);
+    QR_LAUNCH("part_scatter", part_scatter_atomic_kernel<true>, dim3((unsigned)ceil_div64(cap1, SORT_TILE), b * RADIX),
+              dim3(SORT_THREADS), 0, st, (const uint64_t *)tmp_keys, (const uint32_t *)tmp_ids, part_keys, part_ids,
+              (int64_t)0, 0, 64 - T, lowmask, cur2, cap2, ovf, qr_empty_key(r), (const uint32_t *)cur1, cap1);
+    QR_LAUNCH("bucket_emit", (bucket_finish_kernel<FIN_EMIT>), dim3(nparts, b), dim3(FIN_THREADS), 0, st,
+              (const uint64_t *)part_keys, (const uint32_t *)part_ids, nq, (const uint32_t *)nullptr, nparts,
+              qr_empty_key(r), total_overflow_out, ovf, pairs_out, capacity, (const uint32_t *)cur2, cap2);
     QR_LAUNCH_CHECK("qrlsh_bucket_pairs_emit");
     return QRLSH_OK;
   }

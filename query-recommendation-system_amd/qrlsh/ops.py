@@ -347,8 +347,9 @@ def emit_pairs_fast(keys, r, part_bits=None, one_pass=True, capacity=None):
     words = lib.qrlsh_bucket_part_words(nq, b, T) if one_pass else b * nq
     pk = torch.empty((words,), dtype=torch.int64, device=dev)
     pid = torch.empty((words,), dtype=torch.int32, device=dev)
-    tk = torch.empty_like(keys) if T > 8 else None
-    tid = torch.empty((b, nq), dtype=torch.int32, device=dev) if T > 8 else None
+    twords = (lib.qrlsh_bucket_tmp_words(nq, b, T) if one_pass else b * nq) if T > 8 else 0
+    tk = torch.empty((twords,), dtype=torch.int64, device=dev) if T > 8 else None
+    tid = torch.empty((twords,), dtype=torch.int32, device=dev) if T > 8 else None
     ws = _ws(lib.qrlsh_bucket_workspace_bytes(nq, b, T), dev)
     tot = torch.zeros(2, dtype=torch.int64, device=dev)
     if one_pass:
