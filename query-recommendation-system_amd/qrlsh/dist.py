@@ -41,6 +41,8 @@ from .pipeline import HotPathResult
 class HipBackend:
     """libqrlsh kernels (the product path)."""
 
+    rows_hint = 0   # queries this rank owns (set by the driver): sizes the rows of the pair de-dup
+
     def minhash(self, offsets, rows, table, b):
         return ops.minhash(offsets, rows, table, b=b, want_norm=True, compact=ops.can_compact(table))
 
@@ -50,7 +52,7 @@ class HipBackend:
     def sort_unique(self, words, bit_ranges):
         # bit_ranges = [(0, ib), (32, 32 + ib)]: pair words i << 32 | j
         ib = bit_ranges[0][1]
-        g = ops.row_group_bits(ib)
+        g = ops.row_group_bits(ib, words.numel() / max(1, self.rows_hint or 1))
         grouped, _ = ops.sort_u64(words, None, 32 + g, 32 + ib)  # by i >> g only; rows are finished in LDS
         pairs = ops.row_unique(grouped, g, ib)
         if pairs is None:                                        # a row too long for the LDS image
@@ -185,6 +187,7 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     nql = offsets.numel() - 1
+    be.rows_hint = nql
     if nql * world != nq_total:
         raise ValueError("every rank must own nq_total / world queries (got %d x %d != %d)" % (nql, world, nq_total))
     P = table.P

@@ -269,11 +269,15 @@ def sort_pairs(pairs, nq):
     return p
 
 
-def row_group_bits(id_bits):
+def row_group_bits(id_bits, words_per_row=0.0):
     """low bits of i the grouping sort may ignore (rows of 2^g consecutive i, finished in LDS) when that
-    saves its last 8-bit pass: the id bits left over above a multiple of 8, if at most 4"""
+    saves its last 8-bit pass: the id bits left over above a multiple of 8, if at most 4 -- and only while
+    the grouped rows stay short (words_per_row = emitted pairs per query: rows of 2^g queries beyond ~1000
+    words would all go through the long-row kernel, or overflow it)"""
     g = id_bits % 8
-    return g if (id_bits > 8 and 0 < g <= 4) else 0
+    if not (id_bits > 8 and 0 < g <= 4):
+        return 0
+    return g if words_per_row * (1 << g) <= 1024 else 0
 
 
 def group_pairs_by_i(pairs, nq, group_bits=0):
@@ -308,7 +312,7 @@ def row_unique(grouped, group_bits=0, id_bits=32):
 def unique_pairs(emitted, nq, stats=None):
     """the Python set of lsh.py:41,53: sorted unique words of the emitted pairs (consumed)"""
     ib = id_bits_for(nq)
-    g = row_group_bits(ib)
+    g = row_group_bits(ib, emitted.numel() / max(nq, 1))
     grouped = group_pairs_by_i(emitted, nq, g)
     pairs = row_unique(grouped, g, ib)
     if stats is not None:
