@@ -5,7 +5,6 @@ raw pointers and the current HIP stream to libqrlsh, and returns tensors.  64-bi
 words (band keys, pairs, edge keys) are carried in torch.int64 tensors (bit patterns).
 """
 import ctypes
-import math
 
 import numpy as np
 import torch

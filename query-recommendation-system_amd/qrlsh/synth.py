@@ -3,7 +3,6 @@
 Twin of oracle.synth_csr (bit-identical; tests/test_gpu_parity.py): a pure function of
 (seed, query index), so any shard [q0, q0+nq_local) can be generated independently.
 """
-import ctypes
 import math
 
 import numpy as np

@@ -1,6 +1,5 @@
 """CPU tests of the host layer: the C-ABI library loads and exports every symbol the header
 declares (no compute calls -- there is no GPU here), and the pure-host logic around it."""
-import ctypes
 import math
 import os
 import re
