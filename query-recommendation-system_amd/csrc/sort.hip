@@ -855,18 +855,33 @@ __global__ __launch_bounds__(FIN_THREADS, 8) void bucket_finish_kernel(const uin
   __syncthreads();
   uint32_t so[FIN_IPT];  // arrival number << 16 | slot (both < FIN_CAP <= 65535); 0xFFFFFFFF = empty band
   uint32_t mine = 0;
+  // first probes of all FIN_IPT records go out together (independent LDS atomics in flight), the
+  // occasional second and later probes follow per record, then all the counter increments together
+  uint32_t slot[FIN_IPT];
+  unsigned long long seen[FIN_IPT];
+#pragma unroll
+  for (int j = 0; j < FIN_IPT; ++j) {
+    slot[j] = fin_home(kreg[j]);
+    seen[j] = kreg[j] != ek
+                  ? atomicCAS(&tab[slot[j]], (unsigned long long)ek, (unsigned long long)kreg[j])
+                  : (unsigned long long)ek;
+  }
+#pragma unroll
+  for (int j = 0; j < FIN_IPT; ++j) {
+    if (kreg[j] != ek) {
+      unsigned long long old = seen[j];
+      while (old != ek && old != kreg[j]) {  // FIN_CAP slots for at most FIN_CAP records: a free one always turns up
+        slot[j] = slot[j] + 1 == (uint32_t)FIN_CAP ? 0u : slot[j] + 1;
+        old = atomicCAS(&tab[slot[j]], (unsigned long long)ek, (unsigned long long)kreg[j]);
+      }
+    }
+  }
 #pragma unroll
   for (int j = 0; j < FIN_IPT; ++j) {
     so[j] = 0xFFFFFFFFu;
     if (kreg[j] != ek) {
-      uint32_t slot = fin_home(kreg[j]);
-      for (;;) {  // the table has FIN_CAP slots for at most FIN_CAP records: a free slot always turns up
-        const unsigned long long old = atomicCAS(&tab[slot], (unsigned long long)ek, (unsigned long long)kreg[j]);
-        if (old == ek || old == kreg[j]) break;
-        slot = slot + 1 == (uint32_t)FIN_CAP ? 0u : slot + 1;
-      }
-      const uint32_t o = atomicAdd(&cnt[slot], 1u);
-      so[j] = o << 16 | slot;
+      const uint32_t o = atomicAdd(&cnt[slot[j]], 1u);
+      so[j] = o << 16 | slot[j];
       mine += o;
     }
   }
