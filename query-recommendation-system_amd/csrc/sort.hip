@@ -577,13 +577,19 @@ __global__ __launch_bounds__(SORT_THREADS, 3) void part_scatter_atomic_kernel(
     dr[k] = (d << 16) | (prev + below);
   }
   __syncthreads();
+  // thread d speaks for part d.  The reservation goes out first and its result is not touched until the
+  // tile has been laid out in LDS (which needs local positions only): the atomic's round trip to memory
+  // runs beside the scan, the chaining and the staging.
+  uint32_t tc = 0;
   {
     const int d = threadIdx.x;
-    uint32_t tc = 0;
 #pragma unroll
     for (int i = 0; i < SORT_THREADS / WAVE; ++i) tc += cnt[i][d];
-    // the reservation goes out first: its latency hides behind the scan below
-    const uint32_t gb = tc ? atomicAdd(&cursors[(size_t)batch * nd + d], tc) : 0u;
+  }
+  const uint32_t gb = tc ? atomicAdd(&cursors[(size_t)batch * nd + threadIdx.x], tc) : 0u;
+  uint32_t lstart;
+  {
+    const int d = threadIdx.x;
     uint32_t linc = tc;
 #pragma unroll
     for (int k = 1; k < WAVE; k <<= 1) {
@@ -592,14 +598,10 @@ __global__ __launch_bounds__(SORT_THREADS, 3) void part_scatter_atomic_kernel(
     }
     if (lane == WAVE - 1) lsum[w] = linc;
     __syncthreads();
-    uint32_t lstart = linc - tc;
+    lstart = linc - tc;
 #pragma unroll
     for (int k = 0; k < SORT_THREADS / WAVE; ++k)
       if (k < w) lstart += lsum[k];
-    const bool ok = gb + tc <= cap;
-    if (!ok) atomicOr(overflow, 1u);
-    gok[d] = ok;
-    gdelta[d] = (uint32_t)d * cap + gb - lstart;  // mod 2^32; + the staged position gives the place in the batch
     uint32_t run = lstart;
 #pragma unroll
     for (int i = 0; i < SORT_THREADS / WAVE; ++i) {
@@ -617,6 +619,13 @@ __global__ __launch_bounds__(SORT_THREADS, 3) void part_scatter_atomic_kernel(
       skey[lp] = key[k];
       sval[lp] = val[k] | d << 24;
     }
+  }
+  {
+    const int d = threadIdx.x;
+    const bool ok = gb + tc <= cap;
+    if (!ok) atomicOr(overflow, 1u);
+    gok[d] = ok;
+    gdelta[d] = (uint32_t)d * cap + gb - lstart;  // mod 2^32; + the staged position gives the place in the batch
   }
   __syncthreads();
   const int ntile = (int)min((int64_t)SORT_TILE, n - tbase);
