@@ -217,6 +217,10 @@ def main():
                 roofline["traffic"] = int(traffic[dom]["hbm_bytes_per_launch"])
                 roofline["traffic_source"] = traffic_src
             if dom == "minhash":
+                gather = nnz * P * sb_tab
+                roofline["cache_side"] = {"gather_bytes_per_launch": int(gather),
+                                          "achieved_GBps": round((gather + per_launch) / (kd["avg_ms"] * 1e-3) / 1e9, 1),
+                                          "l2_peak_GBps": 34500.0}
                 roofline["note"] = ("the kernel's work is the gather of |A(q)| rows x 2P bytes per signature from the "
                                     "8 MB permutation table (%.2f GB per launch), which lives in L2 / Infinity Cache; "
                                     "FETCH_SIZE counts the L2 misses the Infinity Cache serves, hence traffic > "
