@@ -67,6 +67,30 @@ def test_host_helpers_match_reference_rules():
     assert ops.hash_bits_for(1_000_000) == 24 and ops.hash_bits_for(10_000_000) == 32 and ops.hash_bits_for(10) == 8
 
 
+def test_host_size_rules():
+    """the host-side rules that pick kernel variants (no GPU needed)"""
+    from qrlsh import _lib, ops
+    lib = _lib.load()
+    # id bits / partition depth / hash bits
+    assert [ops.id_bits_for(n) for n in (1, 2, 3, 1 << 20, (1 << 20) + 1)] == [1, 1, 2, 20, 21]
+    assert ops.part_bits_for(1_000_000) == 8 and ops.part_bits_for(1_200_000) == 9 and ops.part_bits_for(10_000_000) == 12
+    assert ops.part_bits_for(10 ** 9) == 16
+    # rows of 2^g consecutive i: g = id bits above a multiple of 8 when <= 4, and only for short rows
+    assert [ops.row_group_bits(b) for b in (8, 9, 12, 13, 16, 17, 20, 21, 23, 24)] == [0, 1, 4, 0, 0, 1, 4, 0, 0, 0]
+    assert ops.row_group_bits(20, 17.7) == 4 and ops.row_group_bits(20, 64.0) == 4 and ops.row_group_bits(20, 65.0) == 0
+    # wide ids: two ids + 11 score bits must fit 64 bits for the packed edge key
+    assert not ops.wide_ids(26) and ops.wide_ids(27)
+    # scratch sizes grow with the problem and the one-kernel partition needs room for its fixed regions
+    assert lib.qrlsh_bucket_part_words(1_000_000, 32, 8) == 32 * 256 * 6144
+    assert lib.qrlsh_bucket_part_words(1000, 4, 8) >= 4 * 1000
+    assert lib.qrlsh_bucket_tmp_words(1_000_000, 32, 8) == 0
+    assert lib.qrlsh_bucket_tmp_words(10_000_000, 32, 12) > 32 * 10_000_000
+    assert lib.qrlsh_bucket_part_words(10_000_000, 32, 12) == 32 * 4096 * 6144
+    assert lib.qrlsh_bucket_part_words(1 << 25, 2, 9) == 2 * (1 << 25)          # ids past 24 bits: sort-based layout
+    assert lib.qrlsh_row_unique_workspace_bytes(0) > 0
+    assert lib.qrlsh_row_unique_workspace_bytes(10 ** 8) > lib.qrlsh_row_unique_workspace_bytes(10 ** 6)
+
+
 def test_legacy_permutations_follow_the_global_stream():
     from qrlsh import ops
     from oracle import oracle as O
