@@ -215,6 +215,19 @@ int qrlsh_topk_fill(const uint64_t *sorted_edges, const uint32_t *sorted_dst, in
                     int32_t id_bits, const void *workspace, int32_t *src_out, int32_t *dst_out,
                     int32_t *milli_out, void *stream);
 
+/* ---- multi-GPU glue (one process per GPU; qrlsh/dist.py) ----------------------------------------------
+ * remap_pairs: an owner scores pairs (i local, j anywhere) against a row table [its nql local rows | the
+ * fetched remote rows]; out[t] = (i - q0) << 32 | slot(j), slot(j) = j - q0 for a local j, else nql + the
+ * position of j in `need` (the ascending global ids of the fetched rows).
+ * pair_edges: the directed edge keys of scored pairs, forward (src = i) and reverse (src = j) in separate
+ * arrays: packed (id_bits > 0, as qrlsh_score_pairs writes them) or key + payload (id_bits == 0).
+ */
+int qrlsh_remap_pairs(const uint64_t *pairs, int64_t n, int64_t q0, int64_t nql, const uint64_t *need,
+                      int64_t n_need, uint64_t *out, void *stream);
+int qrlsh_pair_edges(const uint64_t *pairs, const int32_t *milli, int64_t n, int32_t id_bits,
+                     uint64_t *fwd_out, uint64_t *rev_out, uint32_t *fwd_dst_out, uint32_t *rev_dst_out,
+                     void *stream);
+
 /* ---- N2: answer sets (the producer of the hot path's input) ---------------------------------
  * Replaces Recommender.compute_shingles, recommender.py:68-103, for queries that are
  * conjunctions of attribute=value: bitmaps[row][words_per_row] holds one bit per table row for

@@ -176,3 +176,74 @@ QRLSH_EXPORT int qrlsh_verify_pairs(const void *sig, int32_t sig_dtype, int32_t 
   QR_LAUNCH_CHECK("qrlsh_verify_pairs");
   return QRLSH_OK;
 }
+
+// ---- multi-GPU glue (qrlsh/dist.py): two small fused kernels instead of ~25 elementwise launches -------
+// An owner scores pairs (i local, j anywhere) against a row table [local rows | fetched remote rows]:
+// out[t] = (i - q0) << 32 | slot(j), slot(j) = j - q0 for a local j, nql + position of j in the ascending
+// list `need` of fetched ids otherwise.
+__global__ __launch_bounds__(256) void remap_pairs_kernel(const uint64_t *__restrict__ pairs, int64_t n, uint64_t q0,
+                                                          uint64_t nql, const uint64_t *__restrict__ need,
+                                                          int64_t n_need, uint64_t *__restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const uint64_t pr = pairs[t], i = pr >> 32, j = pr & 0xFFFFFFFFull;
+  uint64_t slot;
+  if (j >= q0 && j < q0 + nql) {
+    slot = j - q0;
+  } else {
+    int64_t lo = 0, hi = n_need;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (need[mid] < j) lo = mid + 1;
+      else hi = mid;
+    }
+    slot = nql + (uint64_t)lo;
+  }
+  out[t] = (i - q0) << 32 | slot;
+}
+
+// directed edge keys of scored pairs, forward (src = i) and reverse (src = j) in separate arrays, in the
+// packed format (id_bits > 0: src << (id_bits+11) | inv << id_bits | dst) or the key + payload one
+// (id_bits == 0: src << 11 | inv, dst)
+__global__ __launch_bounds__(256) void pair_edges_kernel(const uint64_t *__restrict__ pairs,
+                                                         const int32_t *__restrict__ milli, int64_t n, int id_bits,
+                                                         uint64_t *__restrict__ fwd, uint64_t *__restrict__ rev,
+                                                         uint32_t *__restrict__ fwd_dst,
+                                                         uint32_t *__restrict__ rev_dst) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const uint64_t pr = pairs[t], i = pr >> 32, j = pr & 0xFFFFFFFFull, inv = (uint64_t)(1000 - milli[t]);
+  if (id_bits > 0) {
+    fwd[t] = i << (id_bits + 11) | inv << id_bits | j;
+    rev[t] = j << (id_bits + 11) | inv << id_bits | i;
+  } else {
+    fwd[t] = i << 11 | inv;
+    rev[t] = j << 11 | inv;
+    fwd_dst[t] = (uint32_t)j;
+    rev_dst[t] = (uint32_t)i;
+  }
+}
+
+QRLSH_EXPORT int qrlsh_remap_pairs(const uint64_t *pairs, int64_t n, int64_t q0, int64_t nql, const uint64_t *need,
+                                   int64_t n_need, uint64_t *out, void *stream) {
+  QR_CHECK_ARG(n >= 0 && q0 >= 0 && nql >= 0 && n_need >= 0, "qrlsh_remap_pairs: bad sizes");
+  if (n == 0) return QRLSH_OK;
+  QR_CHECK_ARG(pairs && out && (n_need == 0 || need), "qrlsh_remap_pairs: null pointer");
+  QR_LAUNCH("remap_pairs", remap_pairs_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0,
+            static_cast<hipStream_t>(stream), pairs, n, (uint64_t)q0, (uint64_t)nql, need, n_need, out);
+  QR_LAUNCH_CHECK("qrlsh_remap_pairs");
+  return QRLSH_OK;
+}
+
+QRLSH_EXPORT int qrlsh_pair_edges(const uint64_t *pairs, const int32_t *milli, int64_t n, int32_t id_bits,
+                                  uint64_t *fwd_out, uint64_t *rev_out, uint32_t *fwd_dst_out, uint32_t *rev_dst_out,
+                                  void *stream) {
+  QR_CHECK_ARG(n >= 0 && id_bits >= 0 && id_bits <= 26, "qrlsh_pair_edges: bad arguments (id_bits=%d)", id_bits);
+  if (n == 0) return QRLSH_OK;
+  QR_CHECK_ARG(pairs && milli && fwd_out && rev_out, "qrlsh_pair_edges: null pointer");
+  QR_CHECK_ARG(id_bits > 0 || (fwd_dst_out && rev_dst_out), "qrlsh_pair_edges: id_bits == 0 needs the dst outputs");
+  QR_LAUNCH("pair_edges", pair_edges_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0,
+            static_cast<hipStream_t>(stream), pairs, milli, n, id_bits, fwd_out, rev_out, fwd_dst_out, rev_dst_out);
+  QR_LAUNCH_CHECK("qrlsh_pair_edges");
+  return QRLSH_OK;
+}

@@ -59,6 +59,8 @@ SIGNATURES = {
     "qrlsh_row_norms": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp]),
     "qrlsh_verify_pairs": (ctypes.c_int, [_vp, _i32, _i32, _i32, _vp, _i64, _vp, _vp]),
     "qrlsh_score_pairs": (ctypes.c_int, [_vp, _i32, _vp, _i32, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp]),
+    "qrlsh_remap_pairs": (ctypes.c_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp]),
+    "qrlsh_pair_edges": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "qrlsh_topk_count": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _sz, _vp, _vp]),
     "qrlsh_topk_fill": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "qrlsh_answer_sets_count": (ctypes.c_int, [_vp, _i64, _i64, _vp, _i64, _i32, _vp, _vp]),

@@ -71,6 +71,12 @@ class HipBackend:
         """one stable pass that orders words (and vals) by (word >> lo) // shard"""
         return ops.sort_u64(words, vals, lo, lo + 1, owner_shard=shard)
 
+    def remap_pairs(self, pairs, q0, nql, need):
+        return ops.remap_pairs(pairs, q0, nql, need)
+
+    def pair_edges(self, pairs, milli, id_bits, wide):
+        return ops.pair_edges(pairs, milli, id_bits, wide)
+
     def score_only(self, sig_rows, norm_rows, pairs):
         """milli of pairs whose two halves index rows of sig_rows"""
         return ops.score_pairs(sig_rows, norm_rows, pairs)[0]
@@ -255,7 +261,7 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
 
     # 6. score on the owner; reverse edges -> owner of j
     q0 = rank * nql
-    pi, pj = pairs >> 32, pairs & 0xFFFFFFFF
+    pj = pairs & 0xFFFFFFFF
     if gathered is None:
         # which rows of other ranks do my pairs touch?  (i is local by construction)
         remote = (pj < q0) | (pj >= q0 + nql)
@@ -272,18 +278,15 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
         stats["remote_rows_fetched"] = int(need.numel())
         sig_rows = torch.cat([sig, rrows]) if need.numel() else sig
         norm_rows = torch.cat([norm2, rnorms]) if need.numel() else norm2
-        slot = torch.where(remote, nql + torch.searchsorted(need, pj), pj - q0) if need.numel() else pj - q0
-        local_pairs = ((pi - q0) << 32) | slot               # both halves index rows of sig_rows
+        local_pairs = be.remap_pairs(pairs, q0, nql, need)    # both halves index rows of sig_rows
     if r > 4 and pairs.numel():   # wide bands: hashed bucket ids -> exact verification on the owner
         keep = be.verify_flags(sig_rows, b, local_pairs).bool()
         if not bool(keep.all()):
-            pairs, local_pairs, pi, pj = pairs[keep], local_pairs[keep], pi[keep], pj[keep]
+            pairs, local_pairs = pairs[keep], local_pairs[keep]
     milli = be.score_only(sig_rows, norm_rows, local_pairs)
-    inv = (1000 - milli).to(torch.int64)
     if wide:
         # key + payload edges (src << 11 | inv, dst): ids of any width
-        fwd_k, fwd_d = (pi << 11) | inv, pj.to(torch.int32)
-        rev_k, rev_d = (pj << 11) | inv, pi.to(torch.int32)
+        (fwd_k, fwd_d), (rev_k, rev_d) = be.pair_edges(pairs, milli, ib, True)
         if pairs.numel():
             rev_k, rev_d = be.group_by_owner(rev_k, 11, nql, rev_d)
         sizes = be.owner_sizes(rev_k, 11, nql, world)
@@ -291,8 +294,7 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
         rd_in = _exchange_var(sizes, rev_d.view(torch.int32), group)
         edges_local = (torch.cat([rk_in, fwd_k]), torch.cat([rd_in, fwd_d]))
     else:
-        fwd = (pi << (ib + 11)) | (inv << ib) | pj
-        rev = (pj << (ib + 11)) | (inv << ib) | pi
+        fwd, rev = be.pair_edges(pairs, milli, ib, False)
         if pairs.numel():
             rev = be.group_by_owner(rev, ib + 11, nql)[0]
         rev_in = _exchange_var(be.owner_sizes(rev, ib + 11, nql, world), rev, group)

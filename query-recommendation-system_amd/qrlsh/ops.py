@@ -474,6 +474,34 @@ def score_pairs(sig, norm2, pairs, want_cos=False, edge_id_bits=None, wide=None)
     return milli, cosv, ((edges, edst) if edst is not None else edges)
 
 
+def remap_pairs(pairs, q0, nql, need):
+    """pairs (i local to [q0, q0+nql), j anywhere) -> (i - q0) << 32 | slot(j) over the row table
+    [local rows | rows of the ascending global ids `need`] (multi-GPU scoring, qrlsh/dist.py)"""
+    lib = _lib.load()
+    _need(pairs, torch.int64, "pairs", 1)
+    _need(need, torch.int64, "need", 1)
+    out = torch.empty_like(pairs)
+    _lib.check(lib.qrlsh_remap_pairs(_ptr(pairs), pairs.numel(), int(q0), int(nql), _ptr(need), need.numel(),
+                                     _ptr(out), _stream()))
+    return out
+
+
+def pair_edges(pairs, milli, id_bits, wide=False):
+    """forward / reverse directed edge keys of scored pairs: (fwd, rev) int64, or with wide ids
+    ((fwd_keys, fwd_dst), (rev_keys, rev_dst))"""
+    lib = _lib.load()
+    _need(pairs, torch.int64, "pairs", 1)
+    _need(milli, torch.int32, "milli", 1)
+    n, dev = pairs.numel(), pairs.device
+    fwd = torch.empty((n,), dtype=torch.int64, device=dev)
+    rev = torch.empty((n,), dtype=torch.int64, device=dev)
+    fd = torch.empty((n,), dtype=torch.int32, device=dev) if wide else None
+    rd = torch.empty((n,), dtype=torch.int32, device=dev) if wide else None
+    _lib.check(lib.qrlsh_pair_edges(_ptr(pairs), _ptr(milli), n, 0 if wide else int(id_bits), _ptr(fwd), _ptr(rev),
+                                    _ptr(fd), _ptr(rd), _stream()))
+    return ((fwd, fd), (rev, rd)) if wide else (fwd, rev)
+
+
 def topk_edges(edges, K, id_bits):
     """Per-query top-K (recommender.py:206-210) from the directed edges written by score_pairs
     (packed int64 keys, or the (keys, dst) tuple of the wide-id format):

@@ -81,6 +81,23 @@ class OracleBackend:
         truth = O.candidates_from_sig(np.ascontiguousarray(sig_rows.numpy()), b)
         return _t(np.isin(p, truth).astype(np.uint8))
 
+    def remap_pairs(self, pairs, q0, nql, need):
+        p = pairs.numpy().view(np.uint64)
+        i, j = (p >> np.uint64(32)).astype(np.int64), (p & np.uint64(0xFFFFFFFF)).astype(np.int64)
+        local = (j >= q0) & (j < q0 + nql)
+        slot = np.where(local, j - q0, nql + np.searchsorted(need.numpy(), j))
+        return _t((((i - q0) << 32) | slot).astype(np.int64))
+
+    def pair_edges(self, pairs, milli, id_bits, wide):
+        p = pairs.numpy().view(np.uint64)
+        i, j = p >> np.uint64(32), p & np.uint64(0xFFFFFFFF)
+        inv = (1000 - milli.numpy()).astype(np.uint64)
+        if wide:
+            return ((_t(((i << np.uint64(11)) | inv).view(np.int64)), _t(j.astype(np.int32))),
+                    (_t(((j << np.uint64(11)) | inv).view(np.int64)), _t(i.astype(np.int32))))
+        sh, ib = np.uint64(id_bits + 11), np.uint64(id_bits)
+        return _t(((i << sh) | (inv << ib) | j).view(np.int64)), _t(((j << sh) | (inv << ib) | i).view(np.int64))
+
     def score_only(self, sig_rows, norm_rows, pairs):
         return _t(O.score_pairs(np.ascontiguousarray(sig_rows.numpy()), pairs.numpy().view(np.uint64), mode=1))
 

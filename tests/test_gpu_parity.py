@@ -460,6 +460,30 @@ def test_sharded_driver_on_gpu_equals_single_gpu(tmp_path, world, mode, backend,
     assert sum(int(o["emitted"]) for o in outs) == res.stats["emitted_pairs"]
 
 
+def test_multi_gpu_glue_kernels_match_numpy():
+    rng = np.random.default_rng(3)
+    nq, q0, nql, n = 100000, 30000, 20000, 50000
+    i = rng.integers(q0, q0 + nql, size=n).astype(np.uint64)
+    j = rng.integers(0, nq, size=n).astype(np.uint64)
+    pairs = (i << np.uint64(32)) | j
+    remote = (j < q0) | (j >= q0 + nql)
+    need = np.unique(j[remote]).astype(np.int64)
+    got = u64(ops.remap_pairs(dev(pairs.view(np.int64)), q0, nql, dev(need)))
+    slot = np.where(remote, nql + np.searchsorted(need, j.astype(np.int64)), j.astype(np.int64) - q0).astype(np.uint64)
+    assert np.array_equal(got, ((i - np.uint64(q0)) << np.uint64(32)) | slot)
+    assert np.array_equal(u64(ops.remap_pairs(dev(pairs[~remote].view(np.int64)), q0, nql, dev(need[:0]))),
+                          ((i[~remote] - np.uint64(q0)) << np.uint64(32)) | (j[~remote] - np.uint64(q0)))
+    milli = rng.integers(0, 1001, size=n).astype(np.int32)
+    inv = (1000 - milli).astype(np.uint64)
+    ib = 17
+    fwd, rev = ops.pair_edges(dev(pairs.view(np.int64)), dev(milli), ib)
+    assert np.array_equal(u64(fwd), (i << np.uint64(ib + 11)) | (inv << np.uint64(ib)) | j)
+    assert np.array_equal(u64(rev), (j << np.uint64(ib + 11)) | (inv << np.uint64(ib)) | i)
+    (fk, fd), (rk, rd) = ops.pair_edges(dev(pairs.view(np.int64)), dev(milli), ib, wide=True)
+    assert np.array_equal(u64(fk), (i << np.uint64(11)) | inv) and np.array_equal(fd.cpu().numpy(), j.astype(np.int32))
+    assert np.array_equal(u64(rk), (j << np.uint64(11)) | inv) and np.array_equal(rd.cpu().numpy(), i.astype(np.int32))
+
+
 # ---------------------------------------------------------------------------- fast bucket path
 def test_fast_bucket_path_equals_general_path():
     rng = np.random.default_rng(11)
