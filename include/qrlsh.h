@@ -154,6 +154,18 @@ int qrlsh_bucket_pairs_emit(const uint64_t *keys, uint64_t *part_keys, uint32_t 
                             uint64_t *pairs_out, uint64_t capacity, uint64_t *total_overflow_out,
                             void *stream);
 
+/* qrlsh_bucket_pairs_emit with the keys of band t, query q at
+ *     keys[(q / key_chunk) * key_chunk_stride + t * key_band_stride + q % key_chunk]
+ * -- what a band-partitioned all-to-all delivers ([rank][band][queries of that rank]: key_chunk = queries
+ * per rank, key_band_stride = key_chunk, key_chunk_stride = bands * key_chunk), so the multi-GPU driver
+ * needs no transposing copy.  key_chunk = 0: plain [b][nq].  Chunked keys need nq <= 2^24. */
+int qrlsh_bucket_pairs_emit_chunked(const uint64_t *keys, int64_t key_chunk, int64_t key_chunk_stride,
+                                    int64_t key_band_stride, uint64_t *part_keys, uint32_t *part_ids,
+                                    uint64_t *tmp_keys, uint32_t *tmp_ids, int64_t nq, int32_t b, int32_t r,
+                                    int32_t part_bits, void *workspace, size_t workspace_bytes,
+                                    uint64_t *pairs_out, uint64_t capacity, uint64_t *total_overflow_out,
+                                    void *stream);
+
 /* unique of a sorted uint64 array (count-then-fill) */
 size_t qrlsh_compact_workspace_bytes(int64_t n);
 int qrlsh_unique_count(const uint64_t *sorted, int64_t n, void *workspace, size_t workspace_bytes,

@@ -528,7 +528,8 @@ __global__ __launch_bounds__(SORT_THREADS, 3) void part_scatter_atomic_kernel(
     const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint64_t *__restrict__ keys_out,
     uint32_t *__restrict__ vals_out, int64_t n_in, int ntiles, int shift, uint32_t dmask,
     uint32_t *__restrict__ cursors, uint32_t cap, uint32_t *__restrict__ overflow, uint64_t ek,
-    const uint32_t *__restrict__ in_counts, uint32_t in_cap) {
+    const uint32_t *__restrict__ in_counts, uint32_t in_cap, int64_t chunk_len, int64_t chunk_stride,
+    int64_t band_stride) {
   __shared__ uint32_t cnt[SORT_THREADS / WAVE][RADIX];
   __shared__ uint32_t lsum[SORT_THREADS / WAVE];
   __shared__ uint32_t gdelta[RADIX];
@@ -543,7 +544,10 @@ __global__ __launch_bounds__(SORT_THREADS, 3) void part_scatter_atomic_kernel(
 #pragma unroll
   for (int i = 0; i < SORT_THREADS / WAVE; ++i) cnt[i][threadIdx.x] = 0;
   __syncthreads();
-  const size_t boff = (size_t)batch * (LEVEL2 ? (size_t)in_cap : (size_t)n);
+  // first step: band `batch` of the key matrix, either plain ([b][n]: band_stride = n) or in chunks of
+  // chunk_len queries chunk_stride words apart (what a band-partitioned all-to-all delivers: [rank][band][nql])
+  const size_t boff = LEVEL2 ? (size_t)batch * in_cap : (size_t)batch * (size_t)(band_stride ? band_stride : n);
+  const bool chunked = !LEVEL2 && chunk_len > 0 && chunk_len < n;
   const int64_t wbase = tbase + (int64_t)w * (WAVE * SORT_IPT);
   const uint32_t nd = dmask + 1u;  // parts per batch
   uint64_t key[SORT_IPT];
@@ -553,7 +557,8 @@ __global__ __launch_bounds__(SORT_THREADS, 3) void part_scatter_atomic_kernel(
 #pragma unroll
   for (int k = 0; k < SORT_IPT; ++k) {
     const int64_t idx = wbase + (int64_t)k * WAVE + lane;
-    key[k] = idx < n ? keys_in[boff + idx] : 0;
+    const size_t at = chunked ? boff + (size_t)(idx / chunk_len) * chunk_stride + (size_t)(idx % chunk_len) : boff + idx;
+    key[k] = idx < n ? keys_in[at] : 0;
     val[k] = LEVEL2 ? (idx < n ? vals_in[boff + idx] : 0u) : (uint32_t)idx;
   }
 #pragma unroll
@@ -1147,6 +1152,25 @@ QRLSH_EXPORT int qrlsh_bucket_pairs_emit(const uint64_t *keys, uint64_t *part_ke
                                          int32_t part_bits, void *workspace, size_t workspace_bytes,
                                          uint64_t *pairs_out, uint64_t capacity, uint64_t *total_overflow_out,
                                          void *stream) {
+  return qrlsh_bucket_pairs_emit_chunked(keys, 0, 0, 0, part_keys, part_ids, tmp_keys, tmp_ids, nq, b, r, part_bits,
+                                         workspace, workspace_bytes, pairs_out, capacity, total_overflow_out, stream);
+}
+
+// The same with the keys of band t, query q at keys[(q / key_chunk) * key_chunk_stride + t * key_band_stride +
+// q % key_chunk] -- the layout a band-partitioned all-to-all delivers ([rank][band][queries of that rank]:
+// key_chunk = queries per rank, key_band_stride = key_chunk, key_chunk_stride = bands * key_chunk) -- so the
+// multi-GPU driver needs no transposing copy.  key_chunk = 0: plain [b][nq].  Chunked keys need the
+// one-kernel partition (nq <= 2^24); otherwise QRLSH_EINVAL (make a plain copy and use the call above).
+QRLSH_EXPORT int qrlsh_bucket_pairs_emit_chunked(const uint64_t *keys, int64_t key_chunk, int64_t key_chunk_stride,
+                                                 int64_t key_band_stride, uint64_t *part_keys, uint32_t *part_ids,
+                                                 uint64_t *tmp_keys, uint32_t *tmp_ids, int64_t nq, int32_t b,
+                                                 int32_t r, int32_t part_bits, void *workspace,
+                                                 size_t workspace_bytes, uint64_t *pairs_out, uint64_t capacity,
+                                                 uint64_t *total_overflow_out, void *stream) {
+  QR_CHECK_ARG(key_chunk >= 0 && key_chunk_stride >= 0 && key_band_stride >= 0,
+               "qrlsh_bucket_pairs_emit_chunked: bad key layout");
+  QR_CHECK_ARG(key_chunk == 0 || (nq <= (1ll << 24) && part_bits >= 8),
+               "qrlsh_bucket_pairs_emit_chunked: chunked keys need nq <= 2^24 (nq=%lld)", (long long)nq);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int rc = bucket_check("qrlsh_bucket_pairs_emit", keys, part_keys, part_ids, tmp_keys, tmp_ids, nq, b, r,
                               part_bits, workspace, workspace_bytes, total_overflow_out, st);
@@ -1166,7 +1190,8 @@ QRLSH_EXPORT int qrlsh_bucket_pairs_emit(const uint64_t *keys, uint64_t *part_ke
     const int ntiles = (int)ceil_div64(nq, SORT_TILE);
     QR_LAUNCH("part_scatter", part_scatter_atomic_kernel<false>, dim3(ntiles, b), dim3(SORT_THREADS), 0, st, keys,
               (const uint32_t *)nullptr, part_keys, part_ids, nq, ntiles, 56, (uint32_t)RADIX - 1u, cursors, cap,
-              reinterpret_cast<uint32_t *>(total_overflow_out + 1), qr_empty_key(r), (const uint32_t *)nullptr, 0u);
+              reinterpret_cast<uint32_t *>(total_overflow_out + 1), qr_empty_key(r), (const uint32_t *)nullptr, 0u,
+              key_chunk, key_chunk_stride, key_band_stride);
     QR_LAUNCH("bucket_emit", (bucket_finish_kernel<FIN_EMIT>), dim3(nparts, b), dim3(FIN_THREADS), 0, st,
               (const uint64_t *)part_keys, (const uint32_t *)part_ids, nq, (const uint32_t *)nullptr, nparts,
               qr_empty_key(r), total_overflow_out, reinterpret_cast<uint32_t *>(total_overflow_out + 1), pairs_out,
@@ -1189,10 +1214,11 @@ QRLSH_EXPORT int qrlsh_bucket_pairs_emit(const uint64_t *keys, uint64_t *part_ke
     const int ntiles = (int)ceil_div64(nq, SORT_TILE);
     QR_LAUNCH("part_scatter", part_scatter_atomic_kernel<false>, dim3(ntiles, b), dim3(SORT_THREADS), 0, st, keys,
               (const uint32_t *)nullptr, tmp_keys, tmp_ids, nq, ntiles, 56, (uint32_t)RADIX - 1u, cur1, cap1, ovf,
-              qr_empty_key(r), (const uint32_t *)nullptr, 0u);
+              qr_empty_key(r), (const uint32_t *)nullptr, 0u, key_chunk, key_chunk_stride, key_band_stride);
     QR_LAUNCH("part_scatter", part_scatter_atomic_kernel<true>, dim3((unsigned)ceil_div64(cap1, SORT_TILE), b * RADIX),
               dim3(SORT_THREADS), 0, st, (const uint64_t *)tmp_keys, (const uint32_t *)tmp_ids, part_keys, part_ids,
-              (int64_t)0, 0, 64 - T, lowmask, cur2, cap2, ovf, qr_empty_key(r), (const uint32_t *)cur1, cap1);
+              (int64_t)0, 0, 64 - T, lowmask, cur2, cap2, ovf, qr_empty_key(r), (const uint32_t *)cur1, cap1,
+              (int64_t)0, (int64_t)0, (int64_t)0);
     QR_LAUNCH("bucket_emit", (bucket_finish_kernel<FIN_EMIT>), dim3(nparts, b), dim3(FIN_THREADS), 0, st,
               (const uint64_t *)part_keys, (const uint32_t *)part_ids, nq, (const uint32_t *)nullptr, nparts,
               qr_empty_key(r), total_overflow_out, ovf, pairs_out, capacity, (const uint32_t *)cur2, cap2);

@@ -47,6 +47,7 @@ SIGNATURES = {
     "qrlsh_bucket_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "qrlsh_bucket_pairs_count": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp, _vp]),
     "qrlsh_bucket_pairs_fill": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "qrlsh_bucket_pairs_emit_chunked": (ctypes.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp, _u64, _vp, _vp]),
     "qrlsh_bucket_part_words": (_sz, [_i64, _i32, _i32]),
     "qrlsh_bucket_tmp_words": (_sz, [_i64, _i32, _i32]),
     "qrlsh_bucket_pairs_emit": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp, _u64, _vp, _vp]),

@@ -49,6 +49,15 @@ class HipBackend:
     def emit_pairs(self, keys, r):
         return ops.emit_pairs_any(keys, r)
 
+    def emit_pairs_chunked(self, recv, world, nb, nql, r):
+        """emit_pairs on the [world][nb][nql] buffer of the band-partitioned exchange, read in place;
+        the transposing copy to [nb][world * nql] is made only if the general path is needed"""
+        if world * nql <= (1 << 24):
+            pairs = ops.emit_pairs_fast(recv, r, chunks=(world, nb, nql))
+            if pairs is not None:
+                return pairs
+        return ops.emit_pairs_any(_owned_bands(recv, world, nb, nql), r)
+
     def sort_unique(self, words, bit_ranges):
         # bit_ranges = [(0, ib), (32, 32 + ib)]: pair words i << 32 | j
         ib = bit_ranges[0][1]
@@ -89,6 +98,11 @@ class HipBackend:
 
     def topk(self, edges, K, id_bits):
         return ops.topk_edges(edges, K, id_bits)
+
+
+def _owned_bands(recv, world, nb, nql):
+    """[world][nb][nql] (as received) -> band-major [nb][world * nql]"""
+    return recv.view(world, nb, nql).permute(1, 0, 2).reshape(nb, world * nql).contiguous()
 
 
 _BG_GROUPS = {}
@@ -221,8 +235,7 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
         in_split = [h - l for (l, h) in ranges]
         recv = torch.empty((world * nb, nql), dtype=torch.int64, device=dev)
         _all_to_all(recv, keys, [nb] * world, in_split, group)
-        owned = recv.view(world, nb, nql).permute(1, 0, 2).reshape(nb, nq_total).contiguous()
-        del recv
+        owned = None            # read in place by emit_pairs_chunked
     else:
         raise ValueError("exchange must be 'all_to_all' or 'all_gather'")
     del keys
@@ -245,7 +258,7 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
     # 4. candidates of the owned bands over all queries
     pair_bits = [(0, ib), (32, 32 + ib)]
     if nb > 0:
-        emitted = be.emit_pairs(owned, r)
+        emitted = be.emit_pairs(owned, r) if owned is not None else be.emit_pairs_chunked(recv, world, nb, nql, r)
         stats["emitted_pairs"] = int(emitted.numel())
         # only order by i (so the list splits by owner); duplicates across this rank's few bands are
         # rare and the owner de-duplicates anyway, so the local unique is not worth its passes
@@ -253,7 +266,7 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
     else:
         stats["emitted_pairs"] = 0
         mine = torch.empty((0,), dtype=torch.int64, device=dev)
-    del owned
+    owned = recv = None
 
     # 5. pairs -> owner of i
     got = _exchange_var(be.owner_sizes(mine, 32, nql, world), mine, group)

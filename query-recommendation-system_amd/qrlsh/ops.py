@@ -333,16 +333,27 @@ def part_bits_for(n):
 _EMIT_HINT = {}   # (nq, b, r) -> pairs emitted by the last call of that shape: the next call's capacity guess
 
 
-def emit_pairs_fast(keys, r, part_bits=None, one_pass=True, capacity=None):
+def emit_pairs_fast(keys, r, part_bits=None, one_pass=True, capacity=None, chunks=None):
     """emit_pairs for unsorted band-major keys through the partition + LDS-finish path.
     Returns the pairs tensor, or None when a part overflowed the LDS image (skewed data).
     one_pass: the parts reserve their output ranges on a device cursor (qrlsh_bucket_pairs_emit), so
     no count pass runs; the output buffer is sized by `capacity` (default: 1.25 x what the last call
     of this shape emitted, else 24 pairs per query) and the call is repeated once, exactly sized,
-    if that was too small.  one_pass=False is the count-then-fill form."""
+    if that was too small.  one_pass=False is the count-then-fill form.
+    chunks=(world, nb, nql): `keys` is the [world][nb][nql] buffer a band-partitioned all-to-all delivers
+    (band t, query q at [q // nql][t][q % nql]); it is read in place (one-pass form, nq <= 2^24)."""
     lib = _lib.load()
-    _need(keys, torch.int64, "keys", 2)
-    b, nq = keys.shape
+    if chunks is not None:
+        world, b, nql = chunks
+        nq = world * nql
+        _need(keys, torch.int64, "keys")
+        if keys.numel() != world * b * nql or not one_pass or nq > (1 << 24):
+            raise ValueError("chunked keys: need world * nb * nql words, the one-pass form and nq <= 2^24")
+        layout = (nql, b * nql, nql)
+    else:
+        _need(keys, torch.int64, "keys", 2)
+        b, nq = keys.shape
+        layout = (0, 0, 0)
     dev = keys.device
     T = part_bits if part_bits is not None else part_bits_for(nq)
     if nq > 6144 * (1 << T):
@@ -361,8 +372,9 @@ def emit_pairs_fast(keys, r, part_bits=None, one_pass=True, capacity=None):
             capacity = _EMIT_HINT[shape] * 5 // 4 + 1024 if shape in _EMIT_HINT else 24 * nq + 1024
         while True:
             pairs = torch.empty((capacity,), dtype=torch.int64, device=dev)
-            _lib.check(lib.qrlsh_bucket_pairs_emit(_ptr(keys), _ptr(pk), _ptr(pid), _ptr(tk), _ptr(tid), nq, b, r, T,
-                                                   _ptr(ws), ws.numel(), _ptr(pairs), capacity, _ptr(tot), _stream()))
+            _lib.check(lib.qrlsh_bucket_pairs_emit_chunked(_ptr(keys), layout[0], layout[1], layout[2], _ptr(pk),
+                                                           _ptr(pid), _ptr(tk), _ptr(tid), nq, b, r, T, _ptr(ws),
+                                                           ws.numel(), _ptr(pairs), capacity, _ptr(tot), _stream()))
             n, overflow = tot.tolist()
             if overflow:
                 return None

@@ -67,6 +67,9 @@ class OracleBackend:
                 s = e
         return _t(np.array(out, dtype=np.int64))
 
+    def emit_pairs_chunked(self, recv, world, nb, nql, r):
+        return self.emit_pairs(qdist._owned_bands(recv, world, nb, nql), r)
+
     def sort_unique(self, words, bit_ranges):
         return _t(np.unique(words.numpy().view(np.uint64)).view(np.int64))
 

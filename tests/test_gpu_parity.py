@@ -506,6 +506,21 @@ def test_fast_bucket_path_equals_general_path():
                 assert np.array_equal(np.sort(u64(fast)), gen)
 
 
+@pytest.mark.parametrize("nq,b,world,T", [(40000, 6, 4, None), (90000, 3, 2, 9), (4096, 5, 8, None)])
+def test_chunked_key_layout_is_read_in_place(nq, b, world, T):
+    """keys as a band-partitioned all-to-all delivers them ([rank][band][queries of the rank]) give the
+    same pairs as the band-major matrix"""
+    rng = np.random.default_rng(nq)
+    k = rng.integers(0, nq // 3, size=(b, nq), dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+    k[1, ::7] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    nql = nq // world
+    recv = np.ascontiguousarray(k.reshape(b, world, nql).transpose(1, 0, 2))      # [world][b][nql]
+    plain = ops.emit_pairs_fast(dev(k.view(np.int64)), 4, part_bits=T)
+    chunked = ops.emit_pairs_fast(dev(recv.view(np.int64)), 4, part_bits=T, chunks=(world, b, nql))
+    assert plain is not None and chunked is not None and chunked.numel() == plain.numel()
+    assert np.array_equal(np.sort(u64(chunked)), np.sort(u64(plain)))
+
+
 def test_overflowing_part_falls_back_to_general_path():
     sig = np.random.default_rng(5).integers(0, 30000, size=(9000, 4)).astype(np.int32)
     sig[1000:8000] = sig[0]                                      # 7001 identical -> one part > FIN_CAP
