@@ -1,19 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- the hot path of SURVEY.md section 8 on synthetic answer sets, on N GPUs of one node.
 
-A step = one pass of the whole hot path (MinHash signatures + band keys -> bucket sort ->
-pair emit -> sort/unique -> pair scoring -> per-query top-K) over one batch of queries whose
+A step = one pass of the whole hot path (MinHash signatures + band keys -> bucket partition ->
+pair emit -> group/unique -> pair scoring -> per-query top-K) over one batch of queries whose
 CSR answer sets and permutation table are already resident in HBM.
 
-Workload at N=1: BASELINE.json configs[1] -- 1 M queries x 128-perm MinHash, 32 bands
-(D = 32768 table rows, mean answer-set size 16, clusters of 8; K = round(log_1.5 nq) = 34).
-For N > 1 every rank owns 1 M queries of an N x 1 M problem (weak scaling): signatures are
-computed per shard, band keys are all-gathered over RCCL, bands are split across ranks for
-the bucket sort, emitted pairs are exchanged to their owner (all-to-all), and owners score.
+Workload (BASELINE.json):
+  N = 1 : configs[2] -- 10 M queries x 128-perm MinHash, 32 bands on ONE MI355X
+          (D = 32768 table rows, mean answer-set size 16, clusters of 8; K = round(log_1.5 nq) = 40).
+  N > 1 : configs[3] -- the SAME 10 M queries sharded N ways (strong scaling, SURVEY 8e: efficiency =
+          T1 / (N * TN) on identical total work): rank g owns ceil(nq/N) consecutive query ids,
+          signatures are computed per shard, bucket ids are exchanged over RCCL (band-partitioned
+          all-to-all by default, --exchange all_gather for the all-gather BASELINE names), emitted
+          pairs go to the owner of their smaller id, owners score, reverse edges go to the owner of
+          the larger id, every rank cuts its own top-K.
+`--nq Q` switches to weak scaling (Q queries per GPU); `--nq-total T` picks another total size.
+configs[1] (1 M queries) is timed as a secondary figure of the N = 1 line, next to the two "next" rows
+of SURVEY 8f that feed / consume the path (answer-set construction N2, prediction loop N1).
 
 Prints ONE JSON line on rank 0 (contract in the task statement).
 """
 import argparse
+import hashlib
+import glob
 import json
 import os
 import sys
@@ -35,11 +44,14 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--nq", type=int, default=1_000_000, help="queries per GPU")
+    ap.add_argument("--nq-total", type=int, default=10_000_000,
+                    help="queries of the whole job, sharded over the GPUs (strong scaling; default configs[2]/[3])")
+    ap.add_argument("--nq", type=int, default=0, help="queries PER GPU (weak scaling); overrides --nq-total")
     ap.add_argument("--perm", type=int, default=128)
     ap.add_argument("--bands", type=int, default=32)
     ap.add_argument("--drows", type=int, default=32768)
-    ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="queries in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=-1,
+                    help="queries in the CPU-baseline sample (-1 = the whole workload up to 10 M, 0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="OpenMP threads of the CPU baseline (box share: 16/GPU)")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--prof-every", type=int, default=5,
@@ -47,8 +59,26 @@ def parse():
                          "serialise back-to-back launches and cost ~10 %% of a step when recorded on all of them)")
     ap.add_argument("--exchange", default="all_to_all", choices=["all_to_all", "all_gather"],
                     help="bucket-id exchange of the sharded path (N > 1)")
+    ap.add_argument("--sig-exchange", default="auto", choices=["auto", "fetch", "all_gather"])
     ap.add_argument("--force-dist", action="store_true", help="run the sharded driver even with one rank (testing)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] / N1 / N2 secondary timings")
     return ap.parse_args()
+
+
+def workload_label(nq_total, P, b, D, world, K, mean_set):
+    """Name the BASELINE.json entry the shape corresponds to (or say that it is none of them)."""
+    shape = "%d queries x %d-perm MinHash, %d bands, D=%d, K=%d, mean |A(q)|=%.2f" % (nq_total, P, b, D, K, mean_set)
+    if (P, b, D) == (128, 32, 32768):
+        if nq_total == 1_000_000 and world == 1:
+            return "configs[1]: " + shape + ", single MI355X"
+        if nq_total == 10_000_000 and world == 1:
+            return "configs[2]: " + shape + ", single MI355X"
+        if nq_total == 10_000_000 and world > 1:
+            tag = "configs[3]" if world == 8 else "configs[3] shape on %d GPUs" % world
+            return "%s: %s, sharded %d-way (%d queries per rank)" % (tag, shape, world, -(-nq_total // world))
+    if (P, b) == (256, 64) and nq_total == 100_000_000:
+        return "configs[4]: " + shape + ", sharded %d-way" % world
+    return "custom shape (none of BASELINE.json's configs): " + shape + ", %d GPU(s)" % world
 
 
 def algorithmic_bytes_per_step(w):
@@ -61,15 +91,16 @@ def algorithmic_bytes_per_step(w):
     sb = w["sig_bytes"]
     rec = b * w["nq_sorted"]                      # (band, query) records this rank buckets
     ib = max(1, (w["nq_total"] - 1).bit_length())
-    g = ib % 8 if (ib > 8 and 0 < ib % 8 <= 4) else 0   # ops.row_group_bits: low bits of i the grouping sort skips
+    g = w.get("group_bits", 0)                    # low bits of i the grouping sort skips (ops.row_group_bits)
     pair_passes = -(-(ib - g) // 8)               # pairs are grouped by i >> g only; rows are finished in LDS
     edge_passes = -(-(ib + 11) // 8)
+    levels = 1 if w.get("part_bits", 8) <= 8 else 2
     out = {
         # CSR in (4 B/row id + 8 B offset); signature row, fused band keys and norm out
         "minhash": 4 * nnz + 8 * nq + (sb * P + 8 * b + 8) * nq,
-        # partition pass of the bucket path: key in, key + id out
+        # partition of the bucket path: key in, key + id out (twice for partitions finer than 256 parts)
         "sort_scatter_kv": (8 + 12) * rec,
-        "part_scatter": (8 + 12) * rec,               # one-kernel partition (atomic room reservation per tile and part)
+        "part_scatter": ((8 + 12) + (levels - 1) * (12 + 12)) * rec,
         "bucket_count": 12 * rec,
         "bucket_fill": 12 * rec + 8 * em,
         "bucket_emit": 12 * rec + 8 * em,             # one-pass form (cursor-reserved output ranges)
@@ -87,17 +118,39 @@ def algorithmic_bytes_per_step(w):
     return out
 
 
-def load_traffic():
+def csrc_fingerprint():
+    """sha256 over the kernel sources the loaded libqrlsh.so was built from: a PMC traffic file under
+    profiles/ is only quoted when it was collected on the same kernels."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "query-recommendation-system_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_traffic(nq_total, P, b):
     """PMC-derived HBM bytes per launch per label (profiles/*_hbm_traffic.json, written by
-    tools/summarise_profile.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)."""
-    import glob
+    tools/summarise_profile.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of THIS
+    command).  -> (by_label, file name, why-not)"""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
-    if not files:
-        return {}, None
-    try:
-        return json.load(open(files[-1])).get("by_label", {}), os.path.basename(files[-1])
-    except Exception:
-        return {}, None
+    fp = csrc_fingerprint()
+    why = "no profiles/*_hbm_traffic.json"
+    for f in reversed(files):
+        try:
+            j = json.load(open(f))
+        except Exception:
+            continue
+        wl = j.get("workload", {})
+        if (wl.get("nq_total"), wl.get("P"), wl.get("b")) != (nq_total, P, b):
+            why = "profiles/ holds no PMC pass of this workload"
+            continue
+        if j.get("csrc_sha") != fp:
+            why = "the PMC pass in profiles/%s was taken on other kernel sources (%s != %s)" % (
+                os.path.basename(f), j.get("csrc_sha"), fp)
+            continue
+        return j.get("by_label", {}), os.path.basename(f), None
+    return {}, None, why
 
 
 def main():
@@ -117,7 +170,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1 or args.force_dist:
+    sharded = world > 1 or args.force_dist
+    if sharded:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -128,23 +182,25 @@ def main():
     from qrlsh import ops, pipeline, _lib
     _lib.load()  # fails loudly if the HIP extension is missing
 
-    nq_local, P, b, D = args.nq, args.perm, args.bands, args.drows
-    nq_total = nq_local * world
+    P, b, D = args.perm, args.bands, args.drows
+    weak = args.nq > 0
+    nq_total = args.nq * world if weak else args.nq_total
+    from qrlsh import dist as qdist
+    q0, nq_local, _ = qdist.shard_range(nq_total, world, rank)
     K = pipeline.max_candidates(nq_total)
-    q0 = rank * nq_local
     off, rows = qrlsh.synth_csr(nq_total, D, seed=0, q0=q0, nq_local=nq_local, device=dev)
     perms = ops.legacy_permutations(P, D, seed=42)
     table = ops.perm_table(perms, dev)
     nnz = int(rows.numel())
 
-    if world == 1 and not args.force_dist:
+    phases = {}
+    if not sharded:
         def step():
             return pipeline.query_similarities(off, rows, table, b, K)
     else:
-        from qrlsh import dist as qdist
-
         def step():
-            return qdist.query_similarities_sharded(off, rows, table, b, K, nq_total, exchange=args.exchange)
+            return qdist.query_similarities_sharded(off, rows, table, b, K, nq_total, exchange=args.exchange,
+                                                    sig_exchange=args.sig_exchange, phases=phases)
 
     def sync():
         if dist is not None:
@@ -155,6 +211,7 @@ def main():
     for _ in range(args.warmup):
         res = step()
     sync()
+    phases.clear()
     every = max(1, args.prof_every)
     prof_steps = 0
     if not args.no_prof:
@@ -176,29 +233,35 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        cnt = torch.tensor([res.pairs.numel(), res.stats.get("emitted_pairs", 0)], dtype=torch.int64, device=dev)
+        cnt = torch.tensor([res.pairs.numel(), res.stats.get("emitted_pairs", 0), res.src.numel()], dtype=torch.int64,
+                           device=dev)
         dist.all_reduce(cnt)
-        unique_pairs, emitted = int(cnt[0].item()), int(cnt[1].item())
+        unique_pairs, emitted, kept_total = (int(x) for x in cnt.tolist())
     else:
         unique_pairs, emitted = int(res.pairs.numel()), int(res.stats.get("emitted_pairs", 0))
+        kept_total = int(res.src.numel())
 
     ms_per_step = elapsed / args.steps * 1e3
     value = nq_total * args.steps / elapsed
 
     out = None
     if rank == 0:
-        w = dict(nq=nq_local, nq_total=nq_total, nq_sorted=nq_local,
+        rec_q = nq_total if not sharded else qdist.shard_range(nq_total, world, 0)[2] * world
+        w = dict(nq=nq_local, nq_total=nq_total, nq_sorted=(rec_q // world if sharded else nq_local),
                  P=P, b=b, nnz=nnz, emitted=int(res.stats.get("emitted_pairs", 0)), unique=int(res.pairs.numel()),
-                 kept=int(res.src.numel()), sig_bytes=2 if res.sig.dtype == torch.int16 else 4)
+                 kept=int(res.src.numel()), sig_bytes=2 if res.sig.dtype == torch.int16 else 4,
+                 group_bits=int(res.stats.get("group_bits", 0)), part_bits=int(res.stats.get("part_bits", 8)))
         ab = algorithmic_bytes_per_step(w)
         sb_tab = 2 if D <= 65536 else 4
-        traffic, traffic_src = load_traffic()
+        traffic, traffic_src, traffic_why = load_traffic(nq_total, P, b) if not sharded else ({}, None, "N > 1")
         kernels = {}
         for name, (cnt_, ms) in prof.items():   # summed over the prof_steps sampled steps of the timed region
             k = {"launches_per_step": cnt_ / prof_steps, "ms_per_step": ms / prof_steps, "avg_ms": ms / cnt_}
             if name in ab and ms > 0:
                 k["algorithmic_bytes_per_step"] = ab[name]
                 k["algorithmic_GBps"] = round(ab[name] / (ms / prof_steps * 1e-3) / 1e9, 1)
+            if name in traffic:
+                k["pmc_hbm_bytes_per_launch"] = int(traffic[name]["hbm_bytes_per_launch"])
             kernels[name] = k
         roofline = None
         if kernels:
@@ -215,7 +278,9 @@ def main():
                                  "algorithmic_bytes_per_launch": int(per_launch)})
             if dom in traffic:
                 roofline["traffic"] = int(traffic[dom]["hbm_bytes_per_launch"])
-                roofline["traffic_source"] = traffic_src
+                roofline["traffic_source"] = "profiles/" + traffic_src
+            else:
+                roofline["traffic_note"] = traffic_why or "kernel not in the PMC summary"
             if dom == "minhash":
                 gather = nnz * P * sb_tab
                 roofline["cache_side"] = {"gather_bytes_per_launch": int(gather),
@@ -228,8 +293,15 @@ def main():
 
         cpu_baseline = None
         recall = None
-        if args.cpu_sample > 0 and world == 1:      # the CPU leg belongs to the one-GPU line only
-            cpu_baseline, recall = cpu_leg(args.cpu_sample, D, P, b, dev, args.cpu_threads)
+        if args.cpu_sample != 0 and world == 1 and not sharded:      # the CPU leg belongs to the one-GPU line only
+            nq_s = min(nq_total, 10_000_000) if args.cpu_sample < 0 else min(args.cpu_sample, nq_total)
+            cpu_baseline, recall = cpu_leg(nq_s, nq_total, D, P, b, dev, args.cpu_threads, res, table)
+        secondary = None
+        if world == 1 and not sharded and not args.no_secondary:
+            del res
+            torch.cuda.empty_cache()
+            secondary = secondary_figures(dev, table, P, b, D)
+            res = None
 
         out = {
             "metric": "MinHash signatures/sec through the whole hot path (signatures -> LSH candidates -> pair scoring -> top-K)",
@@ -240,17 +312,18 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if weak else "strong",
             "vs_baseline": None,
             "dtype": "u16/int32 MinHash values, uint64 keys and pairs (integer); float64 cosine",
             "data": "synthetic (clustered answer sets, SURVEY 8d recipe; seed 0; permutation seed 42)",
-            "config": {"workload": "configs[1]: %d queries/GPU x %d-perm MinHash, %d bands, D=%d, K=%d, mean |A(q)|=%.2f"
-                       % (nq_local, P, b, D, K, nnz / nq_local),
-                       "queries_total": nq_total, "parallelism": "query-sharded x%d" % world,
-                       "bucket_id_exchange": (args.exchange if (world > 1 or args.force_dist) else "none (one GPU)")},
+            "config": {"workload": workload_label(nq_total, P, b, D, world, K, nnz / max(nq_local, 1)),
+                       "queries_total": nq_total, "queries_per_rank": nq_local,
+                       "parallelism": "query-sharded x%d" % world,
+                       "bucket_id_exchange": (args.exchange if sharded else "none (one GPU)")},
             "pairs_scored_per_sec": round(unique_pairs * args.steps / elapsed, 1),
             "unique_pairs": unique_pairs,
             "emitted_pairs": emitted,
+            "kept_edges": kept_total,
             "recall_at_10": recall,
             "kernel_timing": ("HIP events around every kernel of %d of the %d timed steps (every %d%s)"
                               % (prof_steps, args.steps, every, "th" if every > 1 else "st")) if prof_steps else None,
@@ -259,6 +332,16 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
         }
+        if sharded:
+            n = max(1, phases.get("_steps", 1))
+            out["phases_rank0"] = {
+                "note": "rank 0, mean per step; ms from events on the compute stream around each phase (a collective's "
+                        "ms includes waiting for the slowest peer); bytes = what this rank sent",
+                "ms": {k[3:]: round(v / n, 4) for k, v in sorted(phases.items()) if k.startswith("ms:")},
+                "bytes_sent": {k[6:]: int(v / n) for k, v in sorted(phases.items()) if k.startswith("bytes:")},
+                "sig_exchange": res.stats.get("sig_exchange") if res is not None else None}
+        if secondary:
+            out.update(secondary)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -268,7 +351,106 @@ def main():
     os.close(json_fd)
 
 
-def cpu_leg(nq_s, D, P, b, dev, threads):
+def secondary_figures(dev, table, P, b, D):
+    """Figures quoted beside the headline on the one-GPU line: configs[1] (1 M queries) through the same
+    pipeline, and the two SURVEY 8f rows either side of the path -- N2 (answer sets of attribute=value
+    queries -> the CSR the path consumes) and N1 (the prediction loop that consumes its top-K lists)."""
+    import qrlsh
+    from qrlsh import pipeline, _lib, answers, predict
+    out = {}
+    # configs[1]
+    nq = 1_000_000
+    K = pipeline.max_candidates(nq)
+    off, rows = qrlsh.synth_csr(nq, D, seed=0, device=dev)
+    for _ in range(3):
+        res = pipeline.query_similarities(off, rows, table, b, K)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    steps = 20
+    for _ in range(steps):
+        res = pipeline.query_similarities(off, rows, table, b, K)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    out["configs1_1M"] = {"workload": "configs[1]: 1000000 queries x %d-perm, %d bands, D=%d, K=%d" % (P, b, D, K),
+                          "ms_per_step": round(dt * 1e3, 4), "signatures_per_s": round(nq / dt, 1),
+                          "unique_pairs": int(res.pairs.numel()), "steps": steps}
+
+    def timed(label, fn, reps=5):
+        fn()
+        torch.cuda.synchronize()
+        _lib.prof_enable(True)
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        rep = _lib.prof_report()
+        _lib.prof_enable(False)
+        return {k: ms / reps for k, (c, ms) in rep.items()}
+
+    # N2: 1 M two-constraint queries on a 5-feature table of D rows (45 values per feature), answer sets ~ 16 rows
+    rng = np.random.RandomState(7)
+    nfeat, nval = 5, 45
+    cols = [rng.randint(0, nval, size=D).astype(str) for _ in range(nfeat)]
+    index = answers.build_answer_index(cols, dev)
+    qn = 1_000_000
+    qrows = np.full((qn, nfeat), -1, dtype=np.int32)
+    f1 = rng.randint(0, nfeat, size=qn)
+    f2 = (f1 + 1 + rng.randint(0, nfeat - 1, size=qn)) % nfeat
+    for f, v in ((f1, rng.randint(0, nval, size=qn)), (f2, rng.randint(0, nval, size=qn))):
+        base = np.array([index.value_rows[x][1] for x in range(nfeat)])[f]
+        qrows[np.arange(qn), f] = base + np.minimum(v, np.array([len(index.value_rows[x][0]) for x in range(nfeat)])[f] - 1)
+    qd = torch.from_numpy(qrows).to(dev)
+    holder = {}
+
+    def run_n2():
+        holder["csr"] = answers.answer_sets(index, qd)
+    ms = timed("answers", run_n2)
+    nnz2 = int(holder["csr"][1].numel())
+    wpr = index.wpr
+    sweep_bytes = qn * (2 * wpr * 4 + nfeat * 4 + 4 + 64 * 4)     # two bitmap rows in (cache-resident table), slots out
+    compact_bytes = qn * 8 + 2 * 4 * nnz2
+    n2 = {"workload": "%d two-constraint queries, table D=%d, %d features x %d values, mean |A(q)|=%.2f"
+                      % (qn, D, nfeat, nval, nnz2 / qn),
+          "kernels_ms": {k: round(v, 4) for k, v in ms.items()},
+          "queries_per_s": round(qn / (sum(ms.values()) * 1e-3), 1),
+          "algorithmic_bytes": {"answers_sweep": sweep_bytes, "answers_compact": compact_bytes},
+          "note": "the sweep reads 2 bitmap rows of D/8 bytes per query out of L2 (the bitmaps are %.1f MB): cache-side "
+                  "traffic, not HBM" % (index.bitmaps.numel() * 4 / 1e6)}
+    for lab, by in (("answers_sweep", sweep_bytes), ("answers_compact", compact_bytes)):
+        if lab in ms and ms[lab] > 0:
+            n2.setdefault("algorithmic_GBps", {})[lab] = round(by / (ms[lab] * 1e-3) / 1e9, 1)
+    out["next_N2_answer_sets"] = n2
+
+    # N1: 2000 users x 100 000 queries, 75 % of the cells to predict, K = 28 query neighbours, 19 user neighbours
+    nu, nqq = 2000, 100_000
+    Kq, Ku = pipeline.max_candidates(nqq), pipeline.max_candidates(nu)
+    ratings = rng.randint(1, 101, size=(nu, nqq)).astype(np.int32)
+    ratings[rng.rand(nu, nqq) < 0.75] = 0
+    deg = rng.randint(0, Kq + 1, size=nqq)
+    q_src = np.repeat(np.arange(nqq, dtype=np.int32), deg)
+    q_dst = rng.randint(0, nqq, size=q_src.size).astype(np.int32)
+    q_mil = np.sort(rng.randint(0, 1001, size=q_src.size).astype(np.int32))[::-1].copy()
+    usims = {u: {"indexes": rng.randint(0, nu, size=Ku), "values": np.round(rng.rand(Ku), 3)} for u in range(nu)}
+    rt = torch.from_numpy(ratings).to(dev)
+    qs, qdst, qm = (torch.from_numpy(x).to(dev) for x in (q_src, q_dst, q_mil))
+
+    def run_n1():
+        holder["pred"] = predict.fill_predictions(rt, qs, qdst, qm, usims, device=dev)
+    ms1 = timed("predict", run_n1, reps=3)
+    zero = int((ratings == 0).sum())
+    pb = nu * nqq * 8 + zero * ((deg.mean() + Ku) * 4) + q_src.size * 12       # matrix in/out + the gathered ratings + lists
+    pk = ms1.get("predict", 0.0)
+    out["next_N1_prediction_loop"] = {
+        "workload": "%d users x %d queries, %d cells to predict, <=%d query / %d user neighbours" % (nu, nqq, zero, Kq, Ku),
+        "kernels_ms": {k: round(v, 4) for k, v in ms1.items()},
+        "cells_per_s": round(zero / (pk * 1e-3), 1) if pk else None,
+        "algorithmic_bytes": int(pb),
+        "algorithmic_GBps": round(pb / (pk * 1e-3) / 1e9, 1) if pk else None,
+        "note": "algorithmic bytes = matrix read + written once, one 4-byte rating gather per neighbour of a predicted "
+                "cell, the neighbour lists once"}
+    return out
+
+
+def cpu_leg(nq_s, nq_total, D, P, b, dev, threads, res_full, table):
     """CPU baseline (oracle = a C port of the reference's algorithm, OpenMP) on a bounded
     sample of the same workload, and recall@10 of the GPU path against it."""
     import qrlsh
@@ -292,19 +474,29 @@ def cpu_leg(nq_s, D, P, b, dev, threads):
     t1 = time.perf_counter()
     keys = O.band_keys(sig, b)
     pairs = O.candidates(keys, P // b)
+    del keys
     t2 = time.perf_counter()
     milli = O.score_pairs(sig, pairs, mode=1)
     s, d, v = O.topk(pairs, milli, K)
     t3 = time.perf_counter()
-    off = torch.from_numpy(ho).to(dev)
-    rows = torch.from_numpy(hr).to(dev)
-    res = pipeline.query_similarities(off, rows, ops.perm_table(perms, dev), b, K)
+    if nq_s == nq_total:
+        res = res_full                       # the sample IS the benchmarked workload: check the timed run's own output
+    else:
+        off = torch.from_numpy(ho).to(dev)
+        rows = torch.from_numpy(hr).to(dev)
+        res = pipeline.query_similarities(off, rows, table, b, K)
     torch.cuda.synchronize()
     exact = bool(np.array_equal(res.sig_int32().cpu().numpy(), sig)
                  and np.array_equal(res.pairs.cpu().numpy().view(np.uint64), pairs)
                  and np.array_equal(res.milli.cpu().numpy(), milli))
-    recall = recall_at_k(s, d, v, res.src.cpu().numpy(), res.dst.cpu().numpy(), res.val.cpu().numpy(), 10)
+    gs, gd, gv = res.src.cpu().numpy(), res.dst.cpu().numpy(), res.val.cpu().numpy()
+    topk_exact = bool(np.array_equal(gs, s) and np.array_equal(gd, d) and np.array_equal(gv, v))
+    # recall@10 on the lists of the first 200 000 queries (the tie-aware comparison is a Python loop)
+    rq = min(nq_s, 200_000)
+    ce, cg = int(np.searchsorted(s, rq)), int(np.searchsorted(gs, rq))
+    recall = recall_at_k(s[:ce], d[:ce], v[:ce], gs[:cg], gd[:cg], gv[:cg], 10)
     total = t3 - t0
+    del sig
     # the same port on ONE thread (the reference itself is single-threaded), on a smaller sample
     n1 = min(nq_s, 200_000)
     o1, r1 = O.synth_csr(n1, D, seed=0)
@@ -317,13 +509,14 @@ def cpu_leg(nq_s, D, P, b, dev, threads):
         "value": round(nq_s / total, 1), "unit": "signatures/s", "cores": cores, "kind": "port",
         "single_thread": {"value": round(n1 / (t5 - t4), 1), "unit": "signatures/s", "cores": 1,
                           "sample": "whole hot path on nq=%d, 1 thread" % n1, "seconds": round(t5 - t4, 3)},
-        "sample": "whole hot path on nq=%d queries of the same synthetic recipe (P=%d, b=%d, D=%d), oracle/qr_oracle.c with OpenMP, %d threads"
-                  % (nq_s, P, b, D, cores),
+        "sample": "whole hot path on nq=%d queries of the same synthetic recipe (P=%d, b=%d, D=%d)%s, oracle/qr_oracle.c "
+                  "with OpenMP, %d threads" % (nq_s, P, b, D, " = the benchmarked workload" if nq_s == nq_total else "", cores),
         "seconds": round(total, 3),
         "phases_s": {"signatures": round(t1 - t0, 3), "candidates": round(t2 - t1, 3), "scoring_topk": round(t3 - t2, 3)},
         "minhash_signatures_per_s": round(nq_s / (t1 - t0), 1),
         "pairs_scored_per_s": round(len(pairs) / max(t3 - t2, 1e-9), 1),
-        "gpu_bit_exact_on_sample": exact,
+        "gpu_bit_exact_on_sample": exact, "gpu_topk_exact_on_sample": topk_exact,
+        "recall_sample": "tie-aware recall@10 over the lists of the first %d queries" % rq,
     }
     return base, round(recall, 6)
 

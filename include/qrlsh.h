@@ -48,6 +48,10 @@ extern "C" {
 #define QRLSH_SORT_OWNER 8u /* ONE pass whose digit is (key >> bit_lo) / aux: groups words by the rank
                                that owns the id starting at bit_lo (shards of aux ids, <= 256 ranks) */
 
+#define QRLSH_SORT_HOST 16u /* ONE pass over pair words i << 32 | j whose digit is the rank that scores the pair
+                               in the sharded driver: the owner (shards of aux ids) of i or of j, chosen by
+                               the top bit of mix64(pair) -- an even split of the pairs for any id structure */
+
 int qrlsh_version(void);
 const char *qrlsh_last_error(void);
 
@@ -97,7 +101,8 @@ int qrlsh_sort_u64(uint64_t *keys_a, uint64_t *keys_b, uint32_t *vals_a, uint32_
                    void *workspace, size_t workspace_bytes, void *stream);
 
 /* split points of words grouped with QRLSH_SORT_OWNER: bounds_out[g] (device int64 [world+1]) = first
- * position whose owner (word >> bit_lo) / shard is >= g */
+ * position whose owner (word >> bit_lo) / shard is >= g.  bit_lo = -1: pair words grouped with
+ * QRLSH_SORT_HOST (owner = the scoring rank of the pair). */
 int qrlsh_owner_bounds(const uint64_t *words, int64_t n, int32_t bit_lo, uint64_t shard, int32_t world,
                        int64_t *bounds_out, void *stream);
 
@@ -226,6 +231,11 @@ int qrlsh_topk_count(const uint64_t *sorted_edges, int64_t n_edges, int32_t K, i
 int qrlsh_topk_fill(const uint64_t *sorted_edges, const uint32_t *sorted_dst, int64_t n_edges, int32_t K,
                     int32_t id_bits, const void *workspace, int32_t *src_out, int32_t *dst_out,
                     int32_t *milli_out, void *stream);
+/* the same with src_base added to every src written (edge keys whose src field is relative to a rank's
+ * first query id: qrlsh_edges_localize) */
+int qrlsh_topk_fill_based(const uint64_t *sorted_edges, const uint32_t *sorted_dst, int64_t n_edges, int32_t K,
+                          int32_t id_bits, int64_t src_base, const void *workspace, int32_t *src_out,
+                          int32_t *dst_out, int32_t *milli_out, void *stream);
 
 /* ---- multi-GPU glue (one process per GPU; qrlsh/dist.py) ----------------------------------------------
  * remap_pairs: an owner scores pairs (i local, j anywhere) against a row table [its nql local rows | the
@@ -239,6 +249,38 @@ int qrlsh_remap_pairs(const uint64_t *pairs, int64_t n, int64_t q0, int64_t nql,
 int qrlsh_pair_edges(const uint64_t *pairs, const int32_t *milli, int64_t n, int32_t id_bits,
                      uint64_t *fwd_out, uint64_t *rev_out, uint32_t *fwd_dst_out, uint32_t *rev_dst_out,
                      void *stream);
+/* (rev_out == NULL: both edges of pair t go to fwd_out[2t], fwd_out[2t+1] -- and fwd_dst_out likewise --
+ * exactly the layout qrlsh_score_pairs' edge_out has.)
+ *
+ * Sharded scoring.  A pair is scored on the rank qr_pair_host names (QRLSH_SORT_HOST): the owner of one of
+ * its two queries, so at most one of its signature rows is remote.
+ *   idset_*: the set of remote ids a rank's pairs touch, as a bitmap over the nids global ids plus its rank
+ *     structure, kept in `workspace` (qrlsh_idset_workspace_bytes).  build marks both endpoints of every
+ *     pair outside [q0, q0 + nql) and leaves in bounds_out[g] (device int64 [world + 1]) the number of marked
+ *     ids below g * shard -- the per-owner request sizes, bounds_out[world] = the total; list writes the ids
+ *     ascending (the row-fetch request); remap rewrites each pair as slot(i) << 32 | slot(j) into the row
+ *     table [nql local rows | fetched rows in id order]: slot(x) = x - q0 if local, else nql + rank of x.
+ *   gather_rows: the answer to such a request on the owning rank: rows_out[k] = signature row ids[k] - q0
+ *     (row_bytes bytes, a multiple of 16), norms_out[k] its norm.
+ *   score_pairs_split: qrlsh_score_pairs against a row table in two pieces -- row x < split_rows from
+ *     sig / norm2, the others (x - split_rows) from sig_b / norm2_b -- so the fetched rows are never copied.
+ *   edges_localize: directed edges that arrived at the owner of their src (packed, or key + payload when
+ *     edge_dst is given) re-based to its id range: (src - q0) << (id_bits + 11) | inv << id_bits | dst, which
+ *     fits one word whenever bits(nql) + 11 + id_bits <= 64; the top-K sort then orders (src, value, dst)
+ *     completely (edges from several scoring ranks arrive in no useful order). */
+size_t qrlsh_idset_workspace_bytes(int64_t nids);
+int qrlsh_idset_build(const uint64_t *pairs, int64_t n, int64_t q0, int64_t nql, int64_t nids, int64_t shard,
+                      int32_t world, void *workspace, size_t workspace_bytes, int64_t *bounds_out, void *stream);
+int qrlsh_idset_list(const void *workspace, int64_t nids, uint64_t *ids_out, void *stream);
+int qrlsh_idset_remap(const uint64_t *pairs, int64_t n, int64_t q0, int64_t nql, const void *workspace,
+                      int64_t nids, uint64_t *out, void *stream);
+int qrlsh_gather_rows(const void *sig, int64_t row_bytes, const int64_t *norm2, const uint64_t *ids, int64_t n,
+                      int64_t q0, void *rows_out, int64_t *norms_out, void *stream);
+int qrlsh_score_pairs_split(const void *sig, const int64_t *norm2, int64_t split_rows, const void *sig_b,
+                            const int64_t *norm2_b, int32_t sig_dtype, int32_t P, const uint64_t *pairs,
+                            int64_t n, int32_t *milli_out, void *stream);
+int qrlsh_edges_localize(const uint64_t *edges, const uint32_t *edge_dst, int64_t n, int32_t id_bits, int64_t q0,
+                         int64_t nql, uint64_t *out, void *stream);
 
 /* ---- N2: answer sets (the producer of the hot path's input) ---------------------------------
  * Replaces Recommender.compute_shingles, recommender.py:68-103, for queries that are

@@ -376,20 +376,44 @@ static int cmp_k2(const void *a, const void *b) {
 
 QRO_API int64_t qro_topk(const uint64_t *pairs, const int32_t *milli, int64_t n, int32_t K,
                          int32_t *src, int32_t *dst, int32_t *val) {
-  /* sortable 16-byte records: hi = src << 32 | (2000 - (milli + 1000)), lo = dst */
-  k2_t *k = (k2_t *)malloc((size_t)(n > 0 ? 2 * n : 1) * sizeof(k2_t));
+  /* sortable 16-byte records: hi = src << 32 | (2000 - (milli + 1000)), lo = dst.  The records are
+   * first dealt into NB ranges of src (counting pass), the ranges sorted independently (OpenMP), so
+   * the whole array ends up in (src, inv, dst) order -- same result as one qsort, on all cores. */
+  const int64_t m = 2 * n;
+  k2_t *k = (k2_t *)malloc((size_t)(m > 0 ? m : 1) * sizeof(k2_t));
+  uint32_t maxid = 0;
+  for (int64_t t = 0; t < n; ++t) {
+    uint32_t j = (uint32_t)(pairs[t] & 0xFFFFFFFFu); /* i < j */
+    if (j > maxid) maxid = j;
+  }
+  enum { NB = 4096 };
+  const uint64_t span = (uint64_t)maxid + 1;
+  int64_t *start = (int64_t *)calloc(NB + 1, sizeof(int64_t));
+  for (int64_t t = 0; t < n; ++t) {
+    uint32_t i = (uint32_t)(pairs[t] >> 32), j = (uint32_t)(pairs[t] & 0xFFFFFFFFu);
+    start[(uint64_t)i * NB / span + 1]++;
+    start[(uint64_t)j * NB / span + 1]++;
+  }
+  for (int q = 0; q < NB; ++q) start[q + 1] += start[q];
+  int64_t *cur = (int64_t *)malloc(NB * sizeof(int64_t));
+  memcpy(cur, start, NB * sizeof(int64_t));
   for (int64_t t = 0; t < n; ++t) {
     uint32_t i = (uint32_t)(pairs[t] >> 32), j = (uint32_t)(pairs[t] & 0xFFFFFFFFu);
     uint32_t inv = (uint32_t)(1000 - milli[t]); /* milli in [-1000, 1000] -> inv in [0, 2000] */
-    k[2 * t].hi = ((uint64_t)i << 32) | inv; k[2 * t].lo = j;
-    k[2 * t + 1].hi = ((uint64_t)j << 32) | inv; k[2 * t + 1].lo = i;
+    k2_t *a = &k[cur[(uint64_t)i * NB / span]++], *c = &k[cur[(uint64_t)j * NB / span]++];
+    a->hi = ((uint64_t)i << 32) | inv; a->lo = j;
+    c->hi = ((uint64_t)j << 32) | inv; c->lo = i;
   }
-  qsort(k, (size_t)(2 * n), sizeof(k2_t), cmp_k2);
+#pragma omp parallel for schedule(dynamic, 8)
+  for (int q = 0; q < NB; ++q)
+    if (start[q + 1] - start[q] > 1) qsort(k + start[q], (size_t)(start[q + 1] - start[q]), sizeof(k2_t), cmp_k2);
+  free(cur);
+  free(start);
   int64_t out = 0, run = 0;
-  uint32_t cur = 0;
-  for (int64_t t = 0; t < 2 * n; ++t) {
+  uint32_t cs = 0;
+  for (int64_t t = 0; t < m; ++t) {
     uint32_t s = (uint32_t)(k[t].hi >> 32);
-    if (t == 0 || s != cur) { cur = s; run = 0; }
+    if (t == 0 || s != cs) { cs = s; run = 0; }
     if (run < K) {
       src[out] = (int32_t)s;
       dst[out] = (int32_t)k[t].lo;

@@ -51,6 +51,15 @@ __host__ __device__ static inline uint64_t qr_mix64(uint64_t z) {
   return z ^ (z >> 31);
 }
 
+// The rank that scores candidate pair i << 32 | j in the sharded driver (qrlsh/dist.py): the owner of i or
+// the owner of j (ranks own contiguous shards of `shard` ids), picked by the top bit of mix64(pair).  Always
+// the smaller id would give rank g a share proportional to the ids ABOVE its shard (twice the mean on rank
+// 0, nothing on the last rank); a data-independent coin splits the pairs evenly for any id structure.
+__host__ __device__ static inline uint64_t qr_pair_host(uint64_t pair, uint32_t shard) {
+  const uint64_t id = (qr_mix64(pair) >> 63) ? (pair & 0xFFFFFFFFull) : (pair >> 32);
+  return id / shard;
+}
+
 // key of a band whose r int16 values are all -1 (skipped by get_candidates, lsh.py:47)
 __host__ __device__ static inline uint64_t qr_empty_key(int r) {
   return r >= 4 ? ~0ull : ((1ull << (16 * r)) - 1ull);

@@ -178,7 +178,8 @@ __global__ __launch_bounds__(CMP_THREADS) void compact_fill_kernel(const uint64_
                                                                    uint64_t *__restrict__ out_u64,
                                                                    int32_t *__restrict__ src_out,
                                                                    int32_t *__restrict__ dst_out,
-                                                                   int32_t *__restrict__ milli_out) {
+                                                                   int32_t *__restrict__ milli_out,
+                                                                   int32_t src_base = 0) {
   __shared__ uint32_t wtot[CMP_WAVES];
   const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x >> 6;
   const int64_t base = (int64_t)blockIdx.x * CMP_TILE + (int64_t)w * CMP_PER_WAVE;
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(CMP_THREADS) void compact_fill_kernel(const uint64_
       if (PRED == PRED_UNIQUE) {
         out_u64[p] = v[i];
       } else {
-        src_out[p] = (int32_t)(v[i] >> sh);
+        src_out[p] = (int32_t)(v[i] >> sh) + src_base;
         if (vals) {  // wide ids: key = src << 11 | inv, dst rides as the payload
           dst_out[p] = (int32_t)vals[base + i * WAVE + lane];
           milli_out[p] = 1000 - (int32_t)(v[i] & 0x7FFull);
@@ -702,7 +703,7 @@ QRLSH_EXPORT int qrlsh_row_unique_fill(const uint64_t *tmp, int64_t n, const voi
 QRLSH_EXPORT int qrlsh_topk_count(const uint64_t *sorted_edges, int64_t n_edges, int32_t K, int32_t id_bits,
                                   void *workspace, size_t workspace_bytes, uint64_t *total_out, void *stream) {
   // id_bits == 0 selects the wide-id edge format (src << 11 | inv, dst as payload)
-  QR_CHECK_ARG(K > 0 && id_bits >= 0 && id_bits <= 26, "qrlsh_topk_count: bad K=%d or id_bits=%d (need <= 26)", K,
+  QR_CHECK_ARG(K > 0 && id_bits >= 0 && id_bits <= 32, "qrlsh_topk_count: bad K=%d or id_bits=%d (need <= 32)", K,
                id_bits);
   return compact_count<PRED_TOPK>(sorted_edges, n_edges, K, id_bits + 11, workspace, workspace_bytes, total_out, stream,
                                   "qrlsh_topk_count");
@@ -711,13 +712,22 @@ QRLSH_EXPORT int qrlsh_topk_count(const uint64_t *sorted_edges, int64_t n_edges,
 QRLSH_EXPORT int qrlsh_topk_fill(const uint64_t *sorted_edges, const uint32_t *sorted_dst, int64_t n_edges, int32_t K,
                                  int32_t id_bits, const void *workspace, int32_t *src_out, int32_t *dst_out,
                                  int32_t *milli_out, void *stream) {
-  QR_CHECK_ARG(K > 0 && id_bits >= 0 && id_bits <= 26 && n_edges >= 0, "qrlsh_topk_fill: bad arguments");
+  return qrlsh_topk_fill_based(sorted_edges, sorted_dst, n_edges, K, id_bits, 0, workspace, src_out, dst_out, milli_out,
+                               stream);
+}
+
+QRLSH_EXPORT int qrlsh_topk_fill_based(const uint64_t *sorted_edges, const uint32_t *sorted_dst, int64_t n_edges,
+                                       int32_t K, int32_t id_bits, int64_t src_base, const void *workspace,
+                                       int32_t *src_out, int32_t *dst_out, int32_t *milli_out, void *stream) {
+  QR_CHECK_ARG(K > 0 && id_bits >= 0 && id_bits <= 32 && n_edges >= 0 && src_base >= 0 && src_base < (1ll << 31),
+               "qrlsh_topk_fill: bad arguments");
   QR_CHECK_ARG((id_bits == 0) == (sorted_dst != nullptr), "qrlsh_topk_fill: sorted_dst goes with id_bits == 0");
   if (n_edges == 0) return QRLSH_OK;
   QR_CHECK_ARG(sorted_edges && workspace && src_out && dst_out && milli_out, "qrlsh_topk_fill: null pointer");
   QR_LAUNCH("topk_fill", (compact_fill_kernel<PRED_TOPK>), dim3((unsigned)ceil_div64(n_edges, CMP_TILE)),
                      dim3(CMP_THREADS), 0, static_cast<hipStream_t>(stream), sorted_edges, n_edges, K, id_bits + 11,
-                     id_bits, sorted_dst, static_cast<const uint64_t *>(workspace), nullptr, src_out, dst_out, milli_out);
+                     id_bits, sorted_dst, static_cast<const uint64_t *>(workspace), nullptr, src_out, dst_out, milli_out,
+                     (int32_t)src_base);
   QR_LAUNCH_CHECK("qrlsh_topk_fill");
   return QRLSH_OK;
 }

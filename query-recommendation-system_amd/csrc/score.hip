@@ -28,7 +28,9 @@ __global__ __launch_bounds__(256) void score_pairs_kernel(const SigT *__restrict
                                                           const uint64_t *__restrict__ pairs, int64_t n,
                                                           int32_t *__restrict__ milli, double *__restrict__ cosv,
                                                           uint64_t *__restrict__ edges, int id_bits,
-                                                          uint32_t *__restrict__ edge_dst) {
+                                                          uint32_t *__restrict__ edge_dst,
+                                                          const SigT *__restrict__ sig_b,
+                                                          const int64_t *__restrict__ norm2_b, uint32_t split) {
   constexpr bool IS16 = sizeof(SigT) == 2;
   constexpr int VEC = IS16 ? 8 : 4;
   const int lane = threadIdx.x & (WAVE - 1);
@@ -45,12 +47,13 @@ __global__ __launch_bounds__(256) void score_pairs_kernel(const SigT *__restrict
     const int64_t tn = t + ngroups;
     pr_next = (tn < n) ? pairs[tn] : 0;
     const uint32_t i = (uint32_t)(pr >> 32), j = (uint32_t)pr;
-    const SigT *a = sig + (size_t)i * P;
-    const SigT *c = sig + (size_t)j * P;
+    // row table in two pieces (sharded driver): rows below `split` are the rank's own, the rest were fetched
+    const SigT *a = i < split ? sig + (size_t)i * P : sig_b + (size_t)(i - split) * P;
+    const SigT *c = j < split ? sig + (size_t)j * P : sig_b + (size_t)(j - split) * P;
     int64_t na = 0, nb = 0;
     if (live && lig == 0) {
-      na = norm2[i];
-      nb = norm2[j];
+      na = i < split ? norm2[i] : norm2_b[i - split];
+      nb = j < split ? norm2[j] : norm2_b[j - split];
     }
     int64_t dot = 0;
     if (live) {
@@ -96,6 +99,37 @@ __global__ __launch_bounds__(256) void score_pairs_kernel(const SigT *__restrict
   }
 }
 
+static int score_launch(const void *sig, const void *sig_b, int64_t split, int32_t sig_dtype, const int64_t *norm2,
+                        const int64_t *norm2_b, int32_t P, const uint64_t *pairs, int64_t n, int32_t *milli_out,
+                        double *cos_out, uint64_t *edge_out, int32_t id_bits, uint32_t *edge_dst_out, void *stream) {
+  const int64_t groups_per_block = 256 / SCORE_LPP;
+  int64_t blocks = ceil_div64(n, groups_per_block);
+  if (blocks > 256 * 32) blocks = 256 * 32;  // grid-stride beyond 32 workgroups per CU
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)blocks), block(256);
+  const bool aligned = ((((uintptr_t)sig | (uintptr_t)sig_b) & 15) == 0);
+  const uint32_t sp = split >= (1ll << 32) ? 0xFFFFFFFFu : (uint32_t)split;
+  if (sig_dtype == QRLSH_SIG_U16) {
+    const uint16_t *s16 = static_cast<const uint16_t *>(sig), *s16b = static_cast<const uint16_t *>(sig_b);
+    if (aligned && P % 8 == 0)
+      QR_LAUNCH("score_pairs", (score_pairs_kernel<uint16_t, true>), grid, block, 0, st, s16, norm2, P, pairs, n, milli_out,
+                cos_out, edge_out, id_bits, edge_dst_out, s16b, norm2_b, sp);
+    else
+      QR_LAUNCH("score_pairs", (score_pairs_kernel<uint16_t, false>), grid, block, 0, st, s16, norm2, P, pairs, n, milli_out,
+                cos_out, edge_out, id_bits, edge_dst_out, s16b, norm2_b, sp);
+  } else {
+    const int32_t *s32 = static_cast<const int32_t *>(sig), *s32b = static_cast<const int32_t *>(sig_b);
+    if (aligned && P % 4 == 0)
+      QR_LAUNCH("score_pairs", (score_pairs_kernel<int32_t, true>), grid, block, 0, st, s32, norm2, P, pairs, n, milli_out,
+                cos_out, edge_out, id_bits, edge_dst_out, s32b, norm2_b, sp);
+    else
+      QR_LAUNCH("score_pairs", (score_pairs_kernel<int32_t, false>), grid, block, 0, st, s32, norm2, P, pairs, n, milli_out,
+                cos_out, edge_out, id_bits, edge_dst_out, s32b, norm2_b, sp);
+  }
+  QR_LAUNCH_CHECK("qrlsh_score_pairs");
+  return QRLSH_OK;
+}
+
 QRLSH_EXPORT int qrlsh_score_pairs(const void *sig, int32_t sig_dtype, const int64_t *norm2, int32_t P,
                                    const uint64_t *pairs, int64_t n, int32_t *milli_out, double *cos_out,
                                    uint64_t *edge_out, int32_t id_bits, uint32_t *edge_dst_out, void *stream) {
@@ -106,31 +140,23 @@ QRLSH_EXPORT int qrlsh_score_pairs(const void *sig, int32_t sig_dtype, const int
   if (edge_out && !edge_dst_out)
     QR_CHECK_ARG(id_bits > 0 && id_bits <= 26, "qrlsh_score_pairs: id_bits=%d must be in [1,26] without edge_dst_out", id_bits);
   QR_CHECK_ARG(!edge_dst_out || edge_out, "qrlsh_score_pairs: edge_dst_out needs edge_out");
-  const int64_t groups_per_block = 256 / SCORE_LPP;
-  int64_t blocks = ceil_div64(n, groups_per_block);
-  if (blocks > 256 * 32) blocks = 256 * 32;  // grid-stride beyond 32 workgroups per CU
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const dim3 grid((unsigned)blocks), block(256);
-  const bool aligned = (((uintptr_t)sig & 15) == 0);
-  if (sig_dtype == QRLSH_SIG_U16) {
-    const uint16_t *s16 = static_cast<const uint16_t *>(sig);
-    if (aligned && P % 8 == 0)
-      QR_LAUNCH("score_pairs", (score_pairs_kernel<uint16_t, true>), grid, block, 0, st, s16, norm2, P, pairs, n, milli_out,
-                cos_out, edge_out, id_bits, edge_dst_out);
-    else
-      QR_LAUNCH("score_pairs", (score_pairs_kernel<uint16_t, false>), grid, block, 0, st, s16, norm2, P, pairs, n, milli_out,
-                cos_out, edge_out, id_bits, edge_dst_out);
-  } else {
-    const int32_t *s32 = static_cast<const int32_t *>(sig);
-    if (aligned && P % 4 == 0)
-      QR_LAUNCH("score_pairs", (score_pairs_kernel<int32_t, true>), grid, block, 0, st, s32, norm2, P, pairs, n, milli_out,
-                cos_out, edge_out, id_bits, edge_dst_out);
-    else
-      QR_LAUNCH("score_pairs", (score_pairs_kernel<int32_t, false>), grid, block, 0, st, s32, norm2, P, pairs, n, milli_out,
-                cos_out, edge_out, id_bits, edge_dst_out);
-  }
-  QR_LAUNCH_CHECK("qrlsh_score_pairs");
-  return QRLSH_OK;
+  return score_launch(sig, nullptr, 1ll << 32, sig_dtype, norm2, nullptr, P, pairs, n, milli_out, cos_out, edge_out,
+                      id_bits, edge_dst_out, stream);
+}
+
+// The same scores against a row table that comes in two pieces: row index x < split_rows is row x of
+// sig / norm2 (the rank's own queries), the others row x - split_rows of sig_b / norm2_b (rows fetched from
+// other ranks) -- the sharded driver scores without first copying both into one buffer.
+QRLSH_EXPORT int qrlsh_score_pairs_split(const void *sig, const int64_t *norm2, int64_t split_rows, const void *sig_b,
+                                         const int64_t *norm2_b, int32_t sig_dtype, int32_t P, const uint64_t *pairs,
+                                         int64_t n, int32_t *milli_out, void *stream) {
+  QR_CHECK_ARG(n >= 0 && P > 0 && split_rows >= 0 && split_rows < (1ll << 32), "qrlsh_score_pairs_split: bad sizes");
+  QR_CHECK_ARG(sig_dtype == QRLSH_SIG_I32 || sig_dtype == QRLSH_SIG_U16, "qrlsh_score_pairs_split: bad sig_dtype %d",
+               sig_dtype);
+  if (n == 0) return QRLSH_OK;
+  QR_CHECK_ARG(pairs && milli_out && (split_rows == 0 || (sig && norm2)), "qrlsh_score_pairs_split: null pointer");
+  return score_launch(sig, sig_b, split_rows, sig_dtype, norm2, norm2_b, P, pairs, n, milli_out, nullptr, nullptr, 0,
+                      nullptr, stream);
 }
 
 // Exact candidate test for wide bands (r > 4, hashed bucket ids): flags[t] = 1 iff the pair
@@ -213,14 +239,21 @@ __global__ __launch_bounds__(256) void pair_edges_kernel(const uint64_t *__restr
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   const uint64_t pr = pairs[t], i = pr >> 32, j = pr & 0xFFFFFFFFull, inv = (uint64_t)(1000 - milli[t]);
+  // rev == NULL: both edges of pair t next to each other in fwd (2 t, 2 t + 1), as qrlsh_score_pairs writes them
+  uint64_t *f = rev ? fwd + t : fwd + 2 * t, *r = rev ? rev + t : fwd + 2 * t + 1;
   if (id_bits > 0) {
-    fwd[t] = i << (id_bits + 11) | inv << id_bits | j;
-    rev[t] = j << (id_bits + 11) | inv << id_bits | i;
+    *f = i << (id_bits + 11) | inv << id_bits | j;
+    *r = j << (id_bits + 11) | inv << id_bits | i;
   } else {
-    fwd[t] = i << 11 | inv;
-    rev[t] = j << 11 | inv;
-    fwd_dst[t] = (uint32_t)j;
-    rev_dst[t] = (uint32_t)i;
+    *f = i << 11 | inv;
+    *r = j << 11 | inv;
+    if (rev) {
+      fwd_dst[t] = (uint32_t)j;
+      rev_dst[t] = (uint32_t)i;
+    } else {
+      fwd_dst[2 * t] = (uint32_t)j;
+      fwd_dst[2 * t + 1] = (uint32_t)i;
+    }
   }
 }
 
@@ -240,8 +273,8 @@ QRLSH_EXPORT int qrlsh_pair_edges(const uint64_t *pairs, const int32_t *milli, i
                                   void *stream) {
   QR_CHECK_ARG(n >= 0 && id_bits >= 0 && id_bits <= 26, "qrlsh_pair_edges: bad arguments (id_bits=%d)", id_bits);
   if (n == 0) return QRLSH_OK;
-  QR_CHECK_ARG(pairs && milli && fwd_out && rev_out, "qrlsh_pair_edges: null pointer");
-  QR_CHECK_ARG(id_bits > 0 || (fwd_dst_out && rev_dst_out), "qrlsh_pair_edges: id_bits == 0 needs the dst outputs");
+  QR_CHECK_ARG(pairs && milli && fwd_out, "qrlsh_pair_edges: null pointer");
+  QR_CHECK_ARG(id_bits > 0 || (fwd_dst_out && (rev_dst_out || !rev_out)), "qrlsh_pair_edges: id_bits == 0 needs the dst outputs");
   QR_LAUNCH("pair_edges", pair_edges_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0,
             static_cast<hipStream_t>(stream), pairs, milli, n, id_bits, fwd_out, rev_out, fwd_dst_out, rev_dst_out);
   QR_LAUNCH_CHECK("qrlsh_pair_edges");

@@ -32,10 +32,12 @@ __device__ static inline int xcd_tile(int bid, int ntiles) {
 // ceil(2*id_bits / 8) passes instead of 2 * ceil(id_bits / 8)).
 // 3 = owner: (key >> shift) / aux, one pass that groups words by the rank owning the id field
 // (contiguous shards of aux ids each; at most 256 ranks).
-enum { SM_PLAIN = 0, SM_MIX = 1, SM_FOLD = 2, SM_OWNER = 3 };
+// 4 = host: the word is a pair i << 32 | j; digit = the rank that scores it (qr_pair_host: the owner of i
+// or of j, chosen by one bit of mix64(pair) so that every rank gets an equal share whatever the data).
+enum { SM_PLAIN = 0, SM_MIX = 1, SM_FOLD = 2, SM_OWNER = 3, SM_HOST = 4 };
 template <int MODE> __device__ static inline uint32_t digit_of(uint64_t key, int shift, uint32_t fold = 0) {
-  if (MODE == SM_OWNER) {
-    const uint64_t o = (key >> shift) / fold;
+  if (MODE == SM_OWNER || MODE == SM_HOST) {
+    const uint64_t o = MODE == SM_HOST ? qr_pair_host(key, fold) : (key >> shift) / fold;
     return o < RADIX ? (uint32_t)o : RADIX - 1;
   }
   uint64_t x = key;
@@ -93,10 +95,10 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const uint64_t 
           d = part_digit<SPREAD>(key, (key == ek && v) ? (int64_t)v[idx] : idx, shift, ek, dmask);
         else
           d = digit_of<MIX>(key, shift, fold);
-        if (MIX != SM_OWNER) atomicAdd(&h[d], 1u);
+        if (MIX != SM_OWNER && MIX != SM_HOST) atomicAdd(&h[d], 1u);
         dd = d;
       }
-      if (MIX == SM_OWNER) {
+      if (MIX == SM_OWNER || MIX == SM_HOST) {
         // a handful of distinct digits (ranks): one LDS atomic per digit per wave, not per key
         const bool valid = idx < n;
         uint64_t m = __ballot(valid);
@@ -523,7 +525,9 @@ __global__ __launch_bounds__(SORT_THREADS, 3) void part_scatter_staged_kernel(
 // LEVEL2 = true : finer partitions (T > 8 bits) take a second step -- the input is the OUTPUT of a first
 // step, one batch per (band, coarse part): its in_counts[batch] records sit at batch * in_cap and are
 // dealt to nd = 2^(T-8) fine parts by the next bits of the same hash; ids come with the records.
-template <bool LEVEL2>
+// BIGID = false: ids < 2^24, the part number rides in the top byte of the staged id; true (more than 2^24
+// queries): the staged id keeps all 32 bits and the part number is recomputed from (key, id) at write-out.
+template <bool LEVEL2, bool BIGID>
 __global__ __launch_bounds__(SORT_THREADS, 3) void part_scatter_atomic_kernel(
     const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint64_t *__restrict__ keys_out,
     uint32_t *__restrict__ vals_out, int64_t n_in, int ntiles, int shift, uint32_t dmask,
@@ -622,7 +626,7 @@ __global__ __launch_bounds__(SORT_THREADS, 3) void part_scatter_atomic_kernel(
     if (idx < n) {
       const uint32_t d = dr[k] >> 16, lp = cnt[w][d] + (dr[k] & 0xFFFFu);
       skey[lp] = key[k];
-      sval[lp] = val[k] | d << 24;
+      sval[lp] = BIGID ? val[k] : (val[k] | d << 24);
     }
   }
   {
@@ -639,11 +643,13 @@ __global__ __launch_bounds__(SORT_THREADS, 3) void part_scatter_atomic_kernel(
   for (int k = 0; k < SORT_IPT; ++k) {
     const int p = k * SORT_THREADS + threadIdx.x;
     if (p < ntile) {
-      const uint32_t vv = sval[p], d = vv >> 24;
+      const uint32_t vv = sval[p];
+      const uint64_t kk = skey[p];
+      const uint32_t d = BIGID ? part_digit<true>(kk, (int64_t)vv, shift, ek, dmask) : vv >> 24;
       if (gok[d]) {
         const size_t dst = obase + (uint32_t)(gdelta[d] + (uint32_t)p);
-        keys_out[dst] = skey[p];
-        vals_out[dst] = vv & 0xFFFFFFu;
+        keys_out[dst] = kk;
+        vals_out[dst] = BIGID ? vv : (vv & 0xFFFFFFu);
       }
     }
   }
@@ -722,11 +728,17 @@ QRLSH_EXPORT int qrlsh_sort_u64(uint64_t *keys_a, uint64_t *keys_b, uint32_t *va
     return sort_passes<SM_OWNER>(keys_a, keys_b, vals_a, vals_b, n, nbatch, bit_lo, bit_lo + 1, iota, (uint32_t)aux, ghist,
                                  st);
   }
+  if (flags & QRLSH_SORT_HOST) {
+    QR_CHECK_ARG(aux >= 1 && aux < (1ull << 32), "qrlsh_sort_u64: host shard size %llu not in [1, 2^32)",
+                 (unsigned long long)aux);
+    return sort_passes<SM_HOST>(keys_a, keys_b, vals_a, vals_b, n, nbatch, 0, 1, iota, (uint32_t)aux, ghist, st);
+  }
   return sort_passes<SM_PLAIN>(keys_a, keys_b, vals_a, vals_b, n, nbatch, bit_lo, bit_hi, iota, 0, ghist, st);
 }
 
 // bounds_out[g] = first position whose owner (word >> lo) / shard is >= g, g = 0 .. world, for
 // words already grouped by owner (QRLSH_SORT_OWNER): the split points of the variable all-to-all.
+// lo < 0: the words are pairs grouped with QRLSH_SORT_HOST, owner = qr_pair_host
 __global__ void owner_bounds_kernel(const uint64_t *__restrict__ w, int64_t n, int lo, uint64_t shard, int world,
                                     int64_t *__restrict__ bounds_out) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -734,7 +746,8 @@ __global__ void owner_bounds_kernel(const uint64_t *__restrict__ w, int64_t n, i
   int64_t a = 0, b = n;
   while (a < b) {
     const int64_t mid = (a + b) >> 1;
-    if ((w[mid] >> lo) / shard >= (uint64_t)g) b = mid;
+    const uint64_t o = lo < 0 ? qr_pair_host(w[mid], (uint32_t)shard) : (w[mid] >> lo) / shard;
+    if (o >= (uint64_t)g) b = mid;
     else a = mid + 1;
   }
   bounds_out[g] = a;
@@ -742,7 +755,8 @@ __global__ void owner_bounds_kernel(const uint64_t *__restrict__ w, int64_t n, i
 
 QRLSH_EXPORT int qrlsh_owner_bounds(const uint64_t *words, int64_t n, int32_t bit_lo, uint64_t shard, int32_t world,
                                     int64_t *bounds_out, void *stream) {
-  QR_CHECK_ARG(n >= 0 && bit_lo >= 0 && bit_lo < 64 && shard >= 1 && world >= 1 && world <= RADIX && bounds_out,
+  QR_CHECK_ARG(n >= 0 && bit_lo >= -1 && bit_lo < 64 && shard >= 1 && shard < (1ull << 32) && world >= 1 &&
+                   world <= RADIX && bounds_out,
                "qrlsh_owner_bounds: bad arguments");
   QR_CHECK_ARG(n == 0 || words, "qrlsh_owner_bounds: null pointer");
   QR_LAUNCH("owner_bounds", owner_bounds_kernel, dim3((world + 1 + 63) / 64), dim3(64), 0,
@@ -1125,7 +1139,7 @@ static uint32_t fine_region(int64_t nq, int T) {
   const int64_t c = ((nq >> T) * 2 + 128 + 63) / 64 * 64;
   return (uint32_t)(c < FIN_CAP ? c : FIN_CAP);
 }
-static bool one_kernel_partition(int64_t nq, int part_bits) { return nq <= (1ll << 24) && part_bits >= 8; }
+static bool one_kernel_partition(int64_t nq, int part_bits) { return nq < (1ll << 32) && part_bits >= 8; }
 
 // words part_keys / part_ids (and, for part_bits > 8, tmp_keys / tmp_ids) must hold for qrlsh_bucket_pairs_emit
 QRLSH_EXPORT size_t qrlsh_bucket_part_words(int64_t nq, int32_t b, int32_t part_bits) {
@@ -1159,8 +1173,7 @@ QRLSH_EXPORT int qrlsh_bucket_pairs_emit(const uint64_t *keys, uint64_t *part_ke
 // The same with the keys of band t, query q at keys[(q / key_chunk) * key_chunk_stride + t * key_band_stride +
 // q % key_chunk] -- the layout a band-partitioned all-to-all delivers ([rank][band][queries of that rank]:
 // key_chunk = queries per rank, key_band_stride = key_chunk, key_chunk_stride = bands * key_chunk) -- so the
-// multi-GPU driver needs no transposing copy.  key_chunk = 0: plain [b][nq].  Chunked keys need the
-// one-kernel partition (nq <= 2^24); otherwise QRLSH_EINVAL (make a plain copy and use the call above).
+// multi-GPU driver needs no transposing copy.  key_chunk = 0: plain [b][nq].
 QRLSH_EXPORT int qrlsh_bucket_pairs_emit_chunked(const uint64_t *keys, int64_t key_chunk, int64_t key_chunk_stride,
                                                  int64_t key_band_stride, uint64_t *part_keys, uint32_t *part_ids,
                                                  uint64_t *tmp_keys, uint32_t *tmp_ids, int64_t nq, int32_t b,
@@ -1169,8 +1182,6 @@ QRLSH_EXPORT int qrlsh_bucket_pairs_emit_chunked(const uint64_t *keys, int64_t k
                                                  uint64_t *total_overflow_out, void *stream) {
   QR_CHECK_ARG(key_chunk >= 0 && key_chunk_stride >= 0 && key_band_stride >= 0,
                "qrlsh_bucket_pairs_emit_chunked: bad key layout");
-  QR_CHECK_ARG(key_chunk == 0 || (nq <= (1ll << 24) && part_bits >= 8),
-               "qrlsh_bucket_pairs_emit_chunked: chunked keys need nq <= 2^24 (nq=%lld)", (long long)nq);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int rc = bucket_check("qrlsh_bucket_pairs_emit", keys, part_keys, part_ids, tmp_keys, tmp_ids, nq, b, r,
                               part_bits, workspace, workspace_bytes, total_overflow_out, st);
@@ -1179,7 +1190,13 @@ QRLSH_EXPORT int qrlsh_bucket_pairs_emit_chunked(const uint64_t *keys, int64_t k
                (unsigned long long)capacity);
   const int nparts = 1 << part_bits;
   const BucketWs w = bucket_ws(workspace, nq, b, part_bits);
-  if (part_bits == 8 && nq <= (1ll << 24)) {
+  const bool bigid = nq > (1ll << 24);
+#define QR_PART_SCATTER(LEVEL2_, ...)                                                                          \
+  do {                                                                                                         \
+    if (bigid) QR_LAUNCH("part_scatter", (part_scatter_atomic_kernel<LEVEL2_, true>), __VA_ARGS__);            \
+    else QR_LAUNCH("part_scatter", (part_scatter_atomic_kernel<LEVEL2_, false>), __VA_ARGS__);                 \
+  } while (0)
+  if (part_bits == 8 && one_kernel_partition(nq, part_bits)) {
     // one-kernel partition into fixed regions; the part cursors live where the general path keeps `starts`
     const uint32_t cap = part_region(nq);
     uint32_t *cursors = w.starts;
@@ -1188,10 +1205,10 @@ QRLSH_EXPORT int qrlsh_bucket_pairs_emit_chunked(const uint64_t *keys, int64_t k
       return QRLSH_EHIP;
     }
     const int ntiles = (int)ceil_div64(nq, SORT_TILE);
-    QR_LAUNCH("part_scatter", part_scatter_atomic_kernel<false>, dim3(ntiles, b), dim3(SORT_THREADS), 0, st, keys,
-              (const uint32_t *)nullptr, part_keys, part_ids, nq, ntiles, 56, (uint32_t)RADIX - 1u, cursors, cap,
-              reinterpret_cast<uint32_t *>(total_overflow_out + 1), qr_empty_key(r), (const uint32_t *)nullptr, 0u,
-              key_chunk, key_chunk_stride, key_band_stride);
+    QR_PART_SCATTER(false, dim3(ntiles, b), dim3(SORT_THREADS), 0, st, keys, (const uint32_t *)nullptr, part_keys,
+                    part_ids, nq, ntiles, 56, (uint32_t)RADIX - 1u, cursors, cap,
+                    reinterpret_cast<uint32_t *>(total_overflow_out + 1), qr_empty_key(r), (const uint32_t *)nullptr, 0u,
+                    key_chunk, key_chunk_stride, key_band_stride);
     QR_LAUNCH("bucket_emit", (bucket_finish_kernel<FIN_EMIT>), dim3(nparts, b), dim3(FIN_THREADS), 0, st,
               (const uint64_t *)part_keys, (const uint32_t *)part_ids, nq, (const uint32_t *)nullptr, nparts,
               qr_empty_key(r), total_overflow_out, reinterpret_cast<uint32_t *>(total_overflow_out + 1), pairs_out,
@@ -1212,19 +1229,21 @@ QRLSH_EXPORT int qrlsh_bucket_pairs_emit_chunked(const uint64_t *keys, int64_t k
     }
     uint32_t *ovf = reinterpret_cast<uint32_t *>(total_overflow_out + 1);
     const int ntiles = (int)ceil_div64(nq, SORT_TILE);
-    QR_LAUNCH("part_scatter", part_scatter_atomic_kernel<false>, dim3(ntiles, b), dim3(SORT_THREADS), 0, st, keys,
-              (const uint32_t *)nullptr, tmp_keys, tmp_ids, nq, ntiles, 56, (uint32_t)RADIX - 1u, cur1, cap1, ovf,
-              qr_empty_key(r), (const uint32_t *)nullptr, 0u, key_chunk, key_chunk_stride, key_band_stride);
-    QR_LAUNCH("part_scatter", part_scatter_atomic_kernel<true>, dim3((unsigned)ceil_div64(cap1, SORT_TILE), b * RADIX),
-              dim3(SORT_THREADS), 0, st, (const uint64_t *)tmp_keys, (const uint32_t *)tmp_ids, part_keys, part_ids,
-              (int64_t)0, 0, 64 - T, lowmask, cur2, cap2, ovf, qr_empty_key(r), (const uint32_t *)cur1, cap1,
-              (int64_t)0, (int64_t)0, (int64_t)0);
+    QR_PART_SCATTER(false, dim3(ntiles, b), dim3(SORT_THREADS), 0, st, keys, (const uint32_t *)nullptr, tmp_keys,
+                    tmp_ids, nq, ntiles, 56, (uint32_t)RADIX - 1u, cur1, cap1, ovf, qr_empty_key(r),
+                    (const uint32_t *)nullptr, 0u, key_chunk, key_chunk_stride, key_band_stride);
+    QR_PART_SCATTER(true, dim3((unsigned)ceil_div64(cap1, SORT_TILE), b * RADIX), dim3(SORT_THREADS), 0, st,
+                    (const uint64_t *)tmp_keys, (const uint32_t *)tmp_ids, part_keys, part_ids, (int64_t)0, 0, 64 - T,
+                    lowmask, cur2, cap2, ovf, qr_empty_key(r), (const uint32_t *)cur1, cap1, (int64_t)0, (int64_t)0,
+                    (int64_t)0);
     QR_LAUNCH("bucket_emit", (bucket_finish_kernel<FIN_EMIT>), dim3(nparts, b), dim3(FIN_THREADS), 0, st,
               (const uint64_t *)part_keys, (const uint32_t *)part_ids, nq, (const uint32_t *)nullptr, nparts,
               qr_empty_key(r), total_overflow_out, ovf, pairs_out, capacity, (const uint32_t *)cur2, cap2);
     QR_LAUNCH_CHECK("qrlsh_bucket_pairs_emit");
     return QRLSH_OK;
   }
+#undef QR_PART_SCATTER
+  QR_CHECK_ARG(key_chunk == 0, "qrlsh_bucket_pairs_emit_chunked: chunked keys need nq < 2^32");
   bucket_partition(keys, part_keys, part_ids, tmp_keys, tmp_ids, nq, b, r, part_bits, w, st);
   QR_LAUNCH("bucket_emit", (bucket_finish_kernel<FIN_EMIT>), dim3(nparts, b), dim3(FIN_THREADS), 0, st,
             (const uint64_t *)part_keys, (const uint32_t *)part_ids, nq, (const uint32_t *)w.starts, nparts,

@@ -23,6 +23,7 @@ SORT_MIX = 1
 SORT_IOTA = 2
 SORT_FOLD = 4
 SORT_OWNER = 8
+SORT_HOST = 16
 
 _vp = ctypes.c_void_p
 _i32 = ctypes.c_int32
@@ -64,6 +65,14 @@ SIGNATURES = {
     "qrlsh_pair_edges": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "qrlsh_topk_count": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _sz, _vp, _vp]),
     "qrlsh_topk_fill": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "qrlsh_topk_fill_based": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "qrlsh_idset_workspace_bytes": (_sz, [_i64]),
+    "qrlsh_idset_build": (ctypes.c_int, [_vp, _i64, _i64, _i64, _i64, _i64, _i32, _vp, _sz, _vp, _vp]),
+    "qrlsh_idset_list": (ctypes.c_int, [_vp, _i64, _vp, _vp]),
+    "qrlsh_idset_remap": (ctypes.c_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp]),
+    "qrlsh_gather_rows": (ctypes.c_int, [_vp, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "qrlsh_score_pairs_split": (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp]),
+    "qrlsh_edges_localize": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i64, _i64, _vp, _vp]),
     "qrlsh_answer_sets_count": (ctypes.c_int, [_vp, _i64, _i64, _vp, _i64, _i32, _vp, _vp]),
     "qrlsh_answer_sets_fill": (ctypes.c_int, [_vp, _i64, _i64, _vp, _i64, _i32, _vp, _vp, _vp]),
     "qrlsh_answer_sets_sweep": (ctypes.c_int, [_vp, _i64, _i64, _vp, _i64, _i32, _vp, _vp, _vp]),

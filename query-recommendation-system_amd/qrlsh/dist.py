@@ -1,7 +1,8 @@
 """Query-sharded hot path over one process per GPU (torch.distributed; backend "nccl" = RCCL
 over xGMI on the GPU box, "gloo" in the CPU tests).
 
-Rank g owns the contiguous query range [g*nql, (g+1)*nql) and bands {k : k // ceil(b/W) == g}.
+Rank g owns the contiguous query range [g*nql, (g+1)*nql), nql = ceil(nq_total / W) (the last shards are
+padded with empty answer sets, which are never candidates), and bands {k : k // ceil(b/W) == g}.
 
   1. MinHash + band keys + norms on the local shard (no communication).
   2. bucket-id exchange so that cross-shard candidates are found.  Two modes with identical
@@ -10,22 +11,27 @@ Rank g owns the contiguous query range [g*nql, (g+1)*nql) and bands {k : k // ce
                      b/W * nq_total * 8 bytes instead of b * nq_total * 8;
        "all_gather": every rank receives every band key (the exchange BASELINE.json's
                      north_star names), then keeps its bands.
-  3. signatures for scoring.  An owner scores pairs (i local, j anywhere), so it needs the signature
-     rows of the j that live on other ranks.  Two ways, identical results:
-       "fetch" : after step 5 the owner asks the owning ranks for exactly the distinct remote j of
-                 its pairs (ids out, rows + norms back: two all-to-alls).  With p pairs per rank
-                 that is at most p rows however large the world is -- a third of the gather's
-                 volume at 8 ranks on the bench workload, most of it at 2;
+  3. per owned band: bucket partition + pair emission over ALL queries.
+  4. every emitted pair goes to the rank that scores it (variable-size all-to-all): the owner of ONE of
+     its two queries, picked by a bit of mix64(pair) (csrc/common.h: qr_pair_host).  "Always the owner
+     of the smaller id" would give rank g a share proportional to the ids above its shard -- twice the
+     mean on rank 0, nothing on the last rank -- whatever the data; the coin splits evenly.  The scoring
+     rank sorts + uniques what it received -> its share of the global candidate set (the shares are
+     disjoint; their union is the single-GPU candidate list).
+  5. signatures for scoring.  At most one row of a pair is remote.  Two ways, identical results:
+       "fetch" : the scoring rank asks the owners for exactly the distinct remote ids of its pairs (ids
+                 out, rows + norms back);
        "all_gather": every rank receives every row ((W-1)/W * nq_total * 2P bytes per rank) on a
-                 second communicator, asynchronously, beside steps 4-5.
+                 second communicator, asynchronously, beside steps 3-4.
      "auto" (default): all_gather below 4 ranks (one or two peers: the volumes are close and the
-     gather hides behind steps 4-5), fetch from 4 ranks on (p rows against 3 - 7 shards).
-  4. per owned band: bucket partition + pair emission over ALL queries; sorted by i only.
-  5. pairs go to the owner of their smaller query id (variable-size all-to-all); the owner
-     sorts + uniques what it received -> its share of the global candidate set.
-  6. owners score their pairs against the gathered signatures; the reverse edge (j -> i) of
-     every scored pair goes to the owner of j (variable-size all-to-all).
-  7. per-query top-K on the local edges.
+     gather hides behind steps 3-4), fetch from 4 ranks on.
+  6. score; both directed edges of every scored pair go to the owner of their src (variable-size
+     all-to-all; the local share passes through it as a device copy).
+  7. per-query top-K on the edges received: re-based to the local id range, sorted on the whole
+     (src, value, dst) key (edges of one query come from several scoring ranks in no useful order).
+
+Host round trips per step: the emitted-pair count, one per size exchange (pairs, row requests, edges),
+the unique-pair count and the top-K count.  Everything else is a libqrlsh kernel or a collective.
 
 The compute steps go through a small backend object so that the host logic above can be
 exercised on CPU (gloo) with the oracle standing in for the kernels (tests only); the
@@ -52,15 +58,19 @@ class HipBackend:
     def emit_pairs_chunked(self, recv, world, nb, nql, r):
         """emit_pairs on the [world][nb][nql] buffer of the band-partitioned exchange, read in place;
         the transposing copy to [nb][world * nql] is made only if the general path is needed"""
-        if world * nql <= (1 << 24):
-            pairs = ops.emit_pairs_fast(recv, r, chunks=(world, nb, nql))
-            if pairs is not None:
-                return pairs
+        pairs = ops.emit_pairs_fast(recv, r, chunks=(world, nb, nql))
+        if pairs is not None:
+            return pairs
         return ops.emit_pairs_any(_owned_bands(recv, world, nb, nql), r)
 
-    def sort_unique(self, words, bit_ranges):
-        # bit_ranges = [(0, ib), (32, 32 + ib)]: pair words i << 32 | j
-        ib = bit_ranges[0][1]
+    def group_pairs_by_host(self, pairs, nql, world):
+        """pairs ordered by the rank that scores them -> (grouped, bounds int64 [world + 1] on the device)"""
+        if pairs.numel() == 0:
+            return pairs, torch.zeros((world + 1,), dtype=torch.int64, device=pairs.device)
+        g, _ = ops.sort_u64(pairs, None, host_shard=nql)
+        return g, ops.owner_bounds(g, -1, nql, world)
+
+    def sort_unique(self, words, ib):
         g = ops.row_group_bits(ib, words.numel() / max(1, self.rows_hint or 1))
         grouped, _ = ops.sort_u64(words, None, 32 + g, 32 + ib)  # by i >> g only; rows are finished in LDS
         pairs = ops.row_unique(grouped, g, ib)
@@ -69,35 +79,43 @@ class HipBackend:
             pairs = ops.unique_sorted(words)
         return pairs
 
-    def sort_words(self, words, lo, hi):
-        return ops.sort_u64(words, None, lo, hi)[0]
+    def remote_ids(self, pairs, q0, nql, nids, world):
+        return ops.remote_ids(pairs, q0, nql, nids, world)
 
-    def owner_sizes(self, words, lo, shard, world):
-        """per-destination counts of words already grouped by owner = (word >> lo) // shard"""
-        return ops.owner_sizes(words, lo, shard, world) if words.numel() else [0] * world
+    def remote_id_list(self, rid, total):
+        return ops.remote_id_list(rid, total)
 
-    def group_by_owner(self, words, lo, shard, vals=None):
-        """one stable pass that orders words (and vals) by (word >> lo) // shard"""
-        return ops.sort_u64(words, vals, lo, lo + 1, owner_shard=shard)
+    def remap_pairs(self, pairs, rid):
+        return ops.remap_pairs_ids(pairs, rid)
 
-    def remap_pairs(self, pairs, q0, nql, need):
-        return ops.remap_pairs(pairs, q0, nql, need)
+    def gather_rows(self, sig, norm2, ids, q0):
+        return ops.gather_rows(sig, norm2, ids, q0)
 
-    def pair_edges(self, pairs, milli, id_bits, wide):
-        return ops.pair_edges(pairs, milli, id_bits, wide)
-
-    def score_only(self, sig_rows, norm_rows, pairs):
-        """milli of pairs whose two halves index rows of sig_rows"""
-        return ops.score_pairs(sig_rows, norm_rows, pairs)[0]
+    def score(self, sig, norm2, sig_b, norm2_b, pairs):
+        """milli of pairs whose halves index the row table [sig | sig_b]"""
+        if sig_b is None:
+            return ops.score_pairs(sig, norm2, pairs)[0]
+        return ops.score_pairs_split(sig, norm2, sig_b, norm2_b, pairs)
 
     def verify_flags(self, sig_rows, b, pairs):
         return ops.verify_pairs(sig_rows, b, pairs)
 
-    def sort_words_kv(self, words, vals, lo, hi):
-        return ops.sort_u64(words, vals, lo, hi)
+    def edges(self, pairs, milli, ib, wide):
+        """-> (keys int64 [2n], dst int32 [2n] | None), edge 2t = i -> j, 2t + 1 = j -> i"""
+        e = ops.pair_edges_interleaved(pairs, milli, ib, wide)
+        return e if wide else (e, None)
+
+    def group_edges_by_owner(self, keys, dst, lo, nql, world):
+        if keys.numel() == 0:
+            return keys, dst, torch.zeros((world + 1,), dtype=torch.int64, device=keys.device)
+        k, d = ops.sort_u64(keys, dst, lo, lo + 1, owner_shard=nql)
+        return k, d, ops.owner_bounds(k, lo, nql, world)
 
     def topk(self, edges, K, id_bits):
         return ops.topk_edges(edges, K, id_bits)
+
+    def topk_local(self, keys, dst, K, ib, q0, nql):
+        return ops.topk_edges_local(keys, dst, K, ib, q0, nql)
 
 
 def _owned_bands(recv, world, nb, nql):
@@ -122,6 +140,15 @@ def background_group(group=None):
     return _BG_GROUPS[key]
 
 
+def shard_range(nq_total, world, rank):
+    """Rank `rank` owns the query ids [q0, q0 + n_real) of nq_total; every rank's id space is nql =
+    ceil(nq_total / world) wide (the last shards are padded with empty answer sets: their signatures are
+    all -1, their band keys the empty key, so they are never candidates).  -> (q0, n_real, nql)"""
+    nql = -(-nq_total // world)
+    q0 = min(rank * nql, nq_total)
+    return q0, min(nql, nq_total - q0), nql
+
+
 def band_owner_ranges(b, world):
     """contiguous band blocks: rank g owns [lo[g], hi[g])"""
     per = (b + world - 1) // world
@@ -139,9 +166,16 @@ def _staged(t, group):
     return t.is_cuda and dist.get_backend(group) == "gloo"
 
 
+def _bytes_view(out, inp):
+    """compact signature rows are torch.int16, which RCCL does not move: send them as bytes (2-D [rows, bytes],
+    so row-count splits still apply)"""
+    if inp.dtype == torch.int16:
+        return out.view(torch.uint8), inp.view(torch.uint8)
+    return out, inp
+
+
 def _all_gather(out, inp, group=None, async_op=False):
-    if inp.dtype == torch.int16:  # compact signature rows: RCCL has no int16, move them as bytes
-        out, inp = out.view(torch.uint8), inp.view(torch.uint8)
+    out, inp = _bytes_view(out, inp)
     if _staged(inp, group):
         o = torch.empty(out.shape, dtype=out.dtype)
         dist.all_gather_into_tensor(o, inp.cpu(), group=group)
@@ -152,6 +186,7 @@ def _all_gather(out, inp, group=None, async_op=False):
 
 
 def _all_to_all(out, inp, osplit=None, isplit=None, group=None):
+    out, inp = _bytes_view(out, inp)
     if _staged(inp, group):
         o = torch.empty(out.shape, dtype=out.dtype)
         dist.all_to_all_single(o, inp.cpu(), output_split_sizes=osplit, input_split_sizes=isplit, group=group)
@@ -160,67 +195,87 @@ def _all_to_all(out, inp, osplit=None, isplit=None, group=None):
     dist.all_to_all_single(out, inp, output_split_sizes=osplit, input_split_sizes=isplit, group=group)
 
 
-def _exchange_var(chunks_sizes, send, group=None, want_sizes=False):
-    """variable-size all-to-all of a 1-D int64 tensor already ordered by destination.
-    chunks_sizes: python list of per-destination element counts."""
+def _exchange_sizes(bounds, group=None):
+    """bounds: int64 [world + 1] split points (on the compute device) of a buffer ordered by destination.
+    One small all-to-all and ONE read-back -> (send sizes, receive sizes) as host lists."""
     world = dist.get_world_size(group)
-    dev = send.device
-    sizes = torch.tensor(chunks_sizes, dtype=torch.int64, device=dev)
-    rsizes = torch.empty(world, dtype=torch.int64, device=dev)
-    _all_to_all(rsizes, sizes, group=group)
-    rs = rsizes.tolist()
-    recv = torch.empty(int(sum(rs)), dtype=send.dtype, device=dev)
-    _all_to_all(recv, send, rs, list(chunks_sizes), group)
-    return (recv, rs) if want_sizes else recv
+    both = torch.empty((2, world), dtype=torch.int64, device=bounds.device)
+    torch.sub(bounds[1:], bounds[:-1], out=both[0])
+    _all_to_all(both[1], both[0], group=group)
+    s, r = both.tolist()
+    return s, r
 
 
-def _fetch_rows(sig, norm2, need, nql, group=None):
-    """Signature rows + norms of the global query ids `need` (int64, ascending, none of them local):
-    ids go to the ranks that own them, rows and norms come back in the same order.  One payload per
-    row: its signature bytes followed by the 8 bytes of its norm."""
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    dev = sig.device
-    bounds = torch.arange(world + 1, dtype=torch.int64, device=dev) * nql
-    cuts = torch.searchsorted(need, bounds).tolist()
-    sizes = [cuts[g + 1] - cuts[g] for g in range(world)]
-    req, rs = _exchange_var(sizes, need, group, want_sizes=True)
-    local = req - rank * nql
-    rowbytes = sig.shape[1] * sig.element_size()
-    out = torch.empty((local.numel(), rowbytes + 8), dtype=torch.uint8, device=dev)
-    out[:, :rowbytes] = sig.index_select(0, local).view(torch.uint8).view(local.numel(), rowbytes)
-    out[:, rowbytes:] = norm2.index_select(0, local).view(torch.uint8).view(local.numel(), 8)
-    got = torch.empty((need.numel(), rowbytes + 8), dtype=torch.uint8, device=dev)
-    _all_to_all(got, out, sizes, rs, group)
-    rows = got[:, :rowbytes].contiguous().view(sig.dtype).view(need.numel(), sig.shape[1])
-    norms = got[:, rowbytes:].contiguous().view(torch.int64).view(need.numel())
-    return rows, norms
+class _Phases:
+    """per-phase milliseconds (events on the compute stream) and bytes sent, accumulated into a caller's dict"""
+
+    def __init__(self, sink, dev):
+        self.sink = sink
+        self.on = sink is not None and dev.type == "cuda"
+        self.marks = []
+        if self.on:
+            self._mark(None)
+
+    def _mark(self, name):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.marks.append((name, e))
+
+    def done(self, name):
+        if self.on:
+            self._mark(name)
+
+    def sent(self, name, nbytes):
+        if self.sink is not None:
+            self.sink["bytes:" + name] = self.sink.get("bytes:" + name, 0) + int(nbytes)
+
+    def close(self):
+        if self.sink is None:
+            return
+        self.sink["_steps"] = self.sink.get("_steps", 0) + 1
+        if not self.on:
+            return
+        torch.cuda.synchronize()
+        for (_, a), (name, e) in zip(self.marks[:-1], self.marks[1:]):
+            self.sink["ms:" + name] = self.sink.get("ms:" + name, 0.0) + a.elapsed_time(e)
 
 
 def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="all_to_all", backend=None,
-                               group=None, wide_ids=None, sig_exchange="auto"):
-    """Hot path for this rank's query shard; collective over `group`.  Every rank must hold
-    the same number of queries (nq_total % world == 0).  Returns a HotPathResult whose pairs /
-    top-K rows are this rank's share (global query ids); concatenated over ranks in rank
-    order they equal the single-GPU result."""
+                               group=None, wide_ids=None, sig_exchange="auto", phases=None):
+    """Hot path for this rank's query shard (the queries shard_range(nq_total, world, rank) names);
+    collective over `group`.  Returns a HotPathResult: sig / norm2 / top-K rows of this rank's queries
+    (global ids; concatenated over ranks in rank order they equal the single-GPU result) and the
+    candidate pairs this rank scored, sorted (disjoint over ranks; their union is the single-GPU list).
+    phases: a dict that accumulates "ms:<phase>" / "bytes:<collective>" over calls (diagnostics)."""
     be = backend if backend is not None else HipBackend()
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    nql = offsets.numel() - 1
+    _, n_real, nql = shard_range(nq_total, world, rank)
+    if offsets.numel() - 1 != n_real:
+        raise ValueError("rank %d of %d owns %d of the %d queries, got %d answer sets"
+                         % (rank, world, n_real, nq_total, offsets.numel() - 1))
+    if n_real < nql:     # pad the shard with empty answer sets
+        offsets = torch.cat([offsets, offsets[-1:].expand(nql - n_real)])
+    q0 = rank * nql
+    nids = nql * world                       # padded global id space
     be.rows_hint = nql
-    if nql * world != nq_total:
-        raise ValueError("every rank must own nq_total / world queries (got %d x %d != %d)" % (nql, world, nq_total))
     P = table.P
     if P % b != 0:
         raise AssertionError("signature length %d not divisible by b=%d" % (P, b))
+    if exchange not in ("all_to_all", "all_gather"):
+        raise ValueError("exchange must be 'all_to_all' or 'all_gather'")
+    if sig_exchange not in ("auto", "fetch", "all_gather"):
+        raise ValueError("sig_exchange must be 'auto', 'fetch' or 'all_gather'")
     r = P // b
-    ib = ops.id_bits_for(nq_total)
+    ib = ops.id_bits_for(nids)
     wide = ops.wide_ids(ib) if wide_ids is None else wide_ids
     dev = offsets.device
     stats = {}
+    ph = _Phases(phases, dev)
 
     # 1. local signatures
     sig, norm2, keys = be.minhash(offsets, rows, table, b)
+    ph.done("1_minhash")
 
     # 2. bucket-id exchange (short, needed at once: issued before the long gather)
     ranges = band_owner_ranges(b, world)
@@ -229,93 +284,116 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
     if exchange == "all_gather":
         allk = torch.empty((world * b, nql), dtype=torch.int64, device=dev)
         _all_gather(allk, keys, group)
-        owned = allk.view(world, b, nql)[:, lo:hi, :].permute(1, 0, 2).reshape(nb, nq_total).contiguous()
+        owned = allk.view(world, b, nql)[:, lo:hi, :].permute(1, 0, 2).reshape(nb, nids).contiguous()
         del allk
-    elif exchange == "all_to_all":
+        ph.sent("2_bucket_ids", keys.numel() * 8 * (world - 1))
+    else:
         in_split = [h - l for (l, h) in ranges]
         recv = torch.empty((world * nb, nql), dtype=torch.int64, device=dev)
         _all_to_all(recv, keys, [nb] * world, in_split, group)
         owned = None            # read in place by emit_pairs_chunked
-    else:
-        raise ValueError("exchange must be 'all_to_all' or 'all_gather'")
+        ph.sent("2_bucket_ids", (b - nb) * nql * 8)
     del keys
+    ph.done("2_bucket_id_exchange")
 
-    # 3. "all_gather": async gather of the signature rows + norms on the background communicator
-    #    (consumed in step 6; overlaps steps 4-5).  "fetch" / "auto": nothing yet, see step 6.
-    if sig_exchange not in ("auto", "fetch", "all_gather"):
-        raise ValueError("sig_exchange must be 'auto', 'fetch' or 'all_gather'")
-
-    def start_gather():
-        bg = background_group(group)
-        sa = torch.empty((nq_total, P), dtype=sig.dtype, device=dev)
-        na = torch.empty((nq_total,), dtype=torch.int64, device=dev)
-        return sa, na, _all_gather(sa, sig, bg, async_op=True), _all_gather(na, norm2, bg, async_op=True)
-
+    # "all_gather" of the signature rows + norms: asynchronous, on the background communicator
     if sig_exchange == "auto":
         sig_exchange = "all_gather" if world in (2, 3) else "fetch"
-    gathered = start_gather() if sig_exchange == "all_gather" else None
+    gathered = None
+    if sig_exchange == "all_gather":
+        bg = background_group(group)
+        sa = torch.empty((nids, P), dtype=sig.dtype, device=dev)
+        na = torch.empty((nids,), dtype=torch.int64, device=dev)
+        gathered = (sa, na, _all_gather(sa, sig, bg, async_op=True), _all_gather(na, norm2, bg, async_op=True))
+        ph.sent("5_signature_rows", (sig.numel() * sig.element_size() + norm2.numel() * 8) * (world - 1))
+    stats["sig_exchange"] = sig_exchange
 
-    # 4. candidates of the owned bands over all queries
-    pair_bits = [(0, ib), (32, 32 + ib)]
+    # 3. candidates of the owned bands over all queries
     if nb > 0:
         emitted = be.emit_pairs(owned, r) if owned is not None else be.emit_pairs_chunked(recv, world, nb, nql, r)
-        stats["emitted_pairs"] = int(emitted.numel())
-        # only order by i (so the list splits by owner); duplicates across this rank's few bands are
-        # rare and the owner de-duplicates anyway, so the local unique is not worth its passes
-        mine = be.group_by_owner(emitted, 32, nql)[0] if emitted.numel() else emitted
     else:
-        stats["emitted_pairs"] = 0
-        mine = torch.empty((0,), dtype=torch.int64, device=dev)
+        emitted = torch.empty((0,), dtype=torch.int64, device=dev)
+    stats["emitted_pairs"] = int(emitted.numel())
     owned = recv = None
+    ph.done("3_bucket_pairs")
 
-    # 5. pairs -> owner of i
-    got = _exchange_var(be.owner_sizes(mine, 32, nql, world), mine, group)
-    pairs = be.sort_unique(got, pair_bits) if got.numel() else got
+    # 4. pairs -> the rank that scores them.  Duplicates across this rank's few bands are left in: the
+    #    scoring rank de-duplicates anyway, a local unique would cost more passes than the bytes it saves
+    if world > 1:
+        mine, bounds = be.group_pairs_by_host(emitted, nql, world)
+        ssz, rsz = _exchange_sizes(bounds, group)
+        got = torch.empty((sum(rsz),), dtype=torch.int64, device=dev)
+        _all_to_all(got, mine, rsz, ssz, group)
+        ph.sent("4_pairs", (sum(ssz) - ssz[rank]) * 8)
+        del mine
+    else:
+        got = emitted
+    del emitted
+    ph.done("4_pair_exchange")
+    pairs = be.sort_unique(got, ib) if got.numel() else got
+    del got
+    ph.done("4_pair_unique")
 
-    # 6. score on the owner; reverse edges -> owner of j
-    q0 = rank * nql
-    pj = pairs & 0xFFFFFFFF
-    if gathered is None:
-        # which rows of other ranks do my pairs touch?  (i is local by construction)
-        remote = (pj < q0) | (pj >= q0 + nql)
-        need = torch.unique(pj[remote])                     # ascending
-    stats["sig_exchange"] = "all_gather" if gathered is not None else "fetch"
+    # 5. the rows the pairs need
+    sig_b = norm_b = None
     if gathered is not None:
-        sig_rows, norm_rows, h_sig, h_nrm = gathered
+        sa, na, h_sig, h_nrm = gathered
         h_sig.wait()
         h_nrm.wait()
-        local_pairs = pairs                                  # row index == global query id
+        score_sig, score_norm, local_pairs = sa, na, pairs          # row index == global query id
+    elif world == 1:
+        score_sig, score_norm, local_pairs = sig, norm2, pairs
+        stats["remote_rows_fetched"] = 0
     else:
-        if world > 1:
-            rrows, rnorms = _fetch_rows(sig, norm2, need, nql, group)
+        rid = be.remote_ids(pairs, q0, nql, nids, world)
+        ssz, rsz = _exchange_sizes(rid.bounds, group)                # ids I request / ids requested from me
+        need = be.remote_id_list(rid, sum(ssz))
+        req = torch.empty((sum(rsz),), dtype=torch.int64, device=dev)
+        _all_to_all(req, need, rsz, ssz, group)
+        out_rows, out_norms = be.gather_rows(sig, norm2, req, q0)
+        sig_b = torch.empty((need.numel(), P), dtype=sig.dtype, device=dev)
+        norm_b = torch.empty((need.numel(),), dtype=torch.int64, device=dev)
+        _all_to_all(sig_b, out_rows, ssz, rsz, group)
+        _all_to_all(norm_b, out_norms, ssz, rsz, group)
+        ph.sent("5_row_requests", sum(ssz) * 8)
+        ph.sent("5_signature_rows", sum(rsz) * (P * sig.element_size() + 8))
         stats["remote_rows_fetched"] = int(need.numel())
-        sig_rows = torch.cat([sig, rrows]) if need.numel() else sig
-        norm_rows = torch.cat([norm2, rnorms]) if need.numel() else norm2
-        local_pairs = be.remap_pairs(pairs, q0, nql, need)    # both halves index rows of sig_rows
-    if r > 4 and pairs.numel():   # wide bands: hashed bucket ids -> exact verification on the owner
-        keep = be.verify_flags(sig_rows, b, local_pairs).bool()
+        score_sig, score_norm = sig, norm2
+        local_pairs = be.remap_pairs(pairs, rid)                     # both halves index [local rows | fetched rows]
+        del rid, need, req, out_rows, out_norms
+    ph.done("5_signature_rows")
+
+    # 6. score; edges -> owner of their src
+    if r > 4 and pairs.numel():   # wide bands: hashed bucket ids -> exact verification on the scoring rank
+        table_rows = score_sig if sig_b is None else torch.cat([score_sig, sig_b])
+        keep = be.verify_flags(table_rows, b, local_pairs).bool()
+        del table_rows
         if not bool(keep.all()):
             pairs, local_pairs = pairs[keep], local_pairs[keep]
-    milli = be.score_only(sig_rows, norm_rows, local_pairs)
-    if wide:
-        # key + payload edges (src << 11 | inv, dst): ids of any width
-        (fwd_k, fwd_d), (rev_k, rev_d) = be.pair_edges(pairs, milli, ib, True)
-        if pairs.numel():
-            rev_k, rev_d = be.group_by_owner(rev_k, 11, nql, rev_d)
-        sizes = be.owner_sizes(rev_k, 11, nql, world)
-        rk_in = _exchange_var(sizes, rev_k, group)
-        rd_in = _exchange_var(sizes, rev_d.view(torch.int32), group)
-        edges_local = (torch.cat([rk_in, fwd_k]), torch.cat([rd_in, fwd_d]))
+    milli = be.score(score_sig, score_norm, sig_b, norm_b, local_pairs)
+    del local_pairs, sig_b, norm_b, gathered
+    ph.done("6_score")
+    ek, ed = be.edges(pairs, milli, ib, wide)
+    if world > 1:
+        klo = 11 if wide else ib + 11
+        ek, ed, bounds = be.group_edges_by_owner(ek, ed, klo, nql, world)
+        ssz, rsz = _exchange_sizes(bounds, group)
+        ein = torch.empty((sum(rsz),), dtype=torch.int64, device=dev)
+        _all_to_all(ein, ek, rsz, ssz, group)
+        din = None
+        if ed is not None:
+            din = torch.empty((sum(rsz),), dtype=torch.int32, device=dev)
+            _all_to_all(din, ed, rsz, ssz, group)
+        ph.sent("6_edges", (sum(ssz) - ssz[rank]) * (12 if wide else 8))
+        ph.done("6_edge_exchange")
+        # 7. edges of one query now come from several scoring ranks: full-key sort on re-based keys
+        src, dst, val = be.topk_local(ein, din, K, ib, q0, nql)
     else:
-        fwd, rev = be.pair_edges(pairs, milli, ib, False)
-        if pairs.numel():
-            rev = be.group_by_owner(rev, ib + 11, nql)[0]
-        rev_in = _exchange_var(be.owner_sizes(rev, ib + 11, nql, world), rev, group)
-        edges_local = torch.cat([rev_in, fwd])
-
-    # 7. local top-K.  Order matters for the stable top-K sort: per src, reverse edges (dst < src,
-    # ascending by sender rank and pair order) come before forward edges (dst > src, ascending)
-    src, dst, val = be.topk(edges_local, K, ib)
+        # one scoring rank: the edges are in pair order, the stable (src, value) sort of the one-GPU path applies
+        ph.done("6_edge_exchange")
+        src, dst, val = be.topk((ek, ed) if wide else ek, K, ib)
+    ph.done("7_topk")
     stats["unique_pairs"] = int(pairs.numel())
     stats["kept_edges"] = int(src.numel())
-    return HotPathResult(sig, norm2, pairs, milli, src, dst, val, K, b, stats)
+    ph.close()
+    return HotPathResult(sig[:n_real], norm2[:n_real], pairs, milli, src, dst, val, K, b, stats)

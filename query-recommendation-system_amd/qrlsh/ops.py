@@ -159,7 +159,7 @@ def row_norms(sig):
 # ---------------------------------------------------------------------------
 # radix sort
 # ---------------------------------------------------------------------------
-def sort_u64(keys, vals=None, bit_lo=0, bit_hi=64, mix=False, iota=False, fold=0, owner_shard=0):
+def sort_u64(keys, vals=None, bit_lo=0, bit_hi=64, mix=False, iota=False, fold=0, owner_shard=0, host_shard=0):
     """Stable LSD radix sort of each row of keys (int64 bit patterns, unsigned order) over
     bits [bit_lo, bit_hi) (of mix64(key) when mix).  `keys` (and vals) are consumed as one
     of the two ping-pong buffers.  Returns (sorted_keys, sorted_vals | None)."""
@@ -186,6 +186,10 @@ def sort_u64(keys, vals=None, bit_lo=0, bit_hi=64, mix=False, iota=False, fold=0
         flags |= _lib.SORT_OWNER
         aux = int(owner_shard)
         bit_hi = bit_lo + 1
+    if host_shard:    # one pass over pair words: digit = the rank that scores the pair (common.h: qr_pair_host)
+        flags |= _lib.SORT_HOST
+        aux = int(host_shard)
+        bit_lo, bit_hi = 0, 1
     rc = _lib.check(lib.qrlsh_sort_u64(_ptr(k2), _ptr(kb), _ptr(vals), _ptr(vb), n, nbatch, bit_lo, bit_hi, flags, aux,
                                        _ptr(ws), ws.numel(), _stream()))
     ko = kb if rc == 1 else k2
@@ -205,13 +209,19 @@ def hash_bits_for(n):
     return min(32, max(8, (need + 7) // 8 * 8))
 
 
-def owner_sizes(words, bit_lo, shard, world):
-    """per-rank counts of words already grouped by owner = (word >> bit_lo) // shard"""
+def owner_bounds(words, bit_lo, shard, world):
+    """split points (device int64 [world + 1]) of words already grouped by owner = (word >> bit_lo) // shard;
+    bit_lo = -1: pair words grouped by their scoring rank (sort_u64(host_shard=...))"""
     lib = _lib.load()
     _need(words, torch.int64, "words", 1)
     bounds = torch.empty((world + 1,), dtype=torch.int64, device=words.device)
     _lib.check(lib.qrlsh_owner_bounds(_ptr(words), words.numel(), bit_lo, shard, world, _ptr(bounds), _stream()))
-    bl = bounds.tolist()
+    return bounds
+
+
+def owner_sizes(words, bit_lo, shard, world):
+    """per-rank counts of words already grouped by owner (a host list: one read-back)"""
+    bl = owner_bounds(words, bit_lo, shard, world).tolist()
     return [bl[g + 1] - bl[g] for g in range(world)]
 
 
@@ -316,6 +326,7 @@ def unique_pairs(emitted, nq, stats=None):
     pairs = row_unique(grouped, g, ib)
     if stats is not None:
         stats["dedup_path"] = "rows-in-lds" if pairs is not None else "full-sort"
+        stats["group_bits"] = g
     if pairs is None:
         pairs = unique_sorted(sort_pairs(grouped, nq))
     return pairs
@@ -341,14 +352,14 @@ def emit_pairs_fast(keys, r, part_bits=None, one_pass=True, capacity=None, chunk
     of this shape emitted, else 24 pairs per query) and the call is repeated once, exactly sized,
     if that was too small.  one_pass=False is the count-then-fill form.
     chunks=(world, nb, nql): `keys` is the [world][nb][nql] buffer a band-partitioned all-to-all delivers
-    (band t, query q at [q // nql][t][q % nql]); it is read in place (one-pass form, nq <= 2^24)."""
+    (band t, query q at [q // nql][t][q % nql]); it is read in place (one-pass form)."""
     lib = _lib.load()
     if chunks is not None:
         world, b, nql = chunks
         nq = world * nql
         _need(keys, torch.int64, "keys")
-        if keys.numel() != world * b * nql or not one_pass or nq > (1 << 24):
-            raise ValueError("chunked keys: need world * nb * nql words, the one-pass form and nq <= 2^24")
+        if keys.numel() != world * b * nql or not one_pass:
+            raise ValueError("chunked keys: need world * nb * nql words and the one-pass form")
         layout = (nql, b * nql, nql)
     else:
         _need(keys, torch.int64, "keys", 2)
@@ -401,6 +412,7 @@ def emit_pairs_any(keys, r, stats=None):
     emitted = emit_pairs_fast(keys, r)
     if stats is not None:
         stats["bucket_path"] = "partition+lds" if emitted is not None else "general-sort"
+        stats["part_bits"] = part_bits_for(keys.shape[1])
     if emitted is None:
         sk, sid = bucket_sort(keys)
         emitted = emit_pairs(sk, sid, r)
@@ -484,6 +496,113 @@ def score_pairs(sig, norm2, pairs, want_cos=False, edge_id_bits=None, wide=None)
                                      _ptr(cosv), _ptr(edges), edge_id_bits if edge_id_bits is not None else 0,
                                      _ptr(edst), _stream()))
     return milli, cosv, ((edges, edst) if edst is not None else edges)
+
+
+class RemoteIds:
+    """the set of remote query ids a rank's pairs touch (bitmap + rank structure on the device)"""
+
+    def __init__(self, ws, nids, q0, nql, bounds):
+        self.ws, self.nids, self.q0, self.nql, self.bounds = ws, nids, q0, nql, bounds
+
+
+def remote_ids(pairs, q0, nql, nids, world):
+    """-> RemoteIds of the endpoints of `pairs` outside [q0, q0 + nql); .bounds (device int64 [world + 1]) =
+    number of such ids below g * nql, i.e. the per-owner request sizes, [-1] = the total"""
+    lib = _lib.load()
+    _need(pairs, torch.int64, "pairs", 1)
+    dev = pairs.device
+    ws = _ws(lib.qrlsh_idset_workspace_bytes(nids), dev)
+    bounds = torch.empty((world + 1,), dtype=torch.int64, device=dev)
+    _lib.check(lib.qrlsh_idset_build(_ptr(pairs), pairs.numel(), int(q0), int(nql), int(nids), int(nql), world,
+                                     _ptr(ws), ws.numel(), _ptr(bounds), _stream()))
+    return RemoteIds(ws, nids, q0, nql, bounds)
+
+
+def remote_id_list(rid, total):
+    """the ids of the set, ascending (int64 [total])"""
+    lib = _lib.load()
+    out = torch.empty((total,), dtype=torch.int64, device=rid.ws.device)
+    if total:
+        _lib.check(lib.qrlsh_idset_list(_ptr(rid.ws), rid.nids, _ptr(out), _stream()))
+    return out
+
+
+def remap_pairs_ids(pairs, rid):
+    """pairs (global ids) -> slot(i) << 32 | slot(j) over the row table [local rows | rows of rid's ids]"""
+    lib = _lib.load()
+    _need(pairs, torch.int64, "pairs", 1)
+    out = torch.empty_like(pairs)
+    _lib.check(lib.qrlsh_idset_remap(_ptr(pairs), pairs.numel(), int(rid.q0), int(rid.nql), _ptr(rid.ws), rid.nids,
+                                     _ptr(out), _stream()))
+    return out
+
+
+def gather_rows(sig, norm2, ids, q0):
+    """signature rows + norms of the global ids `ids` (all owned by this rank: row = id - q0)"""
+    lib = _lib.load()
+    _need(ids, torch.int64, "ids", 1)
+    n = ids.numel()
+    rows = torch.empty((n, sig.shape[1]), dtype=sig.dtype, device=sig.device)
+    norms = torch.empty((n,), dtype=torch.int64, device=sig.device)
+    _lib.check(lib.qrlsh_gather_rows(_ptr(sig), sig.shape[1] * sig.element_size(), _ptr(norm2), _ptr(ids), n, int(q0),
+                                     _ptr(rows), _ptr(norms), _stream()))
+    return rows, norms
+
+
+def score_pairs_split(sig, norm2, sig_b, norm2_b, pairs):
+    """milli of pairs whose halves index the two-piece row table [sig | sig_b]"""
+    lib = _lib.load()
+    _need(pairs, torch.int64, "pairs", 1)
+    n = pairs.numel()
+    milli = torch.empty((n,), dtype=torch.int32, device=pairs.device)
+    code = _lib.SIG_U16 if sig.dtype == torch.int16 else _lib.SIG_I32
+    _lib.check(lib.qrlsh_score_pairs_split(_ptr(sig), _ptr(norm2), sig.shape[0], _ptr(sig_b), _ptr(norm2_b), code,
+                                           sig.shape[1], _ptr(pairs), n, _ptr(milli), _stream()))
+    return milli
+
+
+def pair_edges_interleaved(pairs, milli, id_bits, wide=False):
+    """both directed edges of every scored pair, [2t] = i -> j, [2t + 1] = j -> i (what score_pairs writes):
+    packed int64 [2n], or with wide ids (keys int64 [2n], dst int32 [2n])"""
+    lib = _lib.load()
+    n, dev = pairs.numel(), pairs.device
+    e = torch.empty((2 * n,), dtype=torch.int64, device=dev)
+    d = torch.empty((2 * n,), dtype=torch.int32, device=dev) if wide else None
+    _lib.check(lib.qrlsh_pair_edges(_ptr(pairs), _ptr(milli), n, 0 if wide else int(id_bits), _ptr(e), None, _ptr(d),
+                                    None, _stream()))
+    return (e, d) if wide else e
+
+
+def local_bits_for(nql):
+    return max(1, int(nql - 1).bit_length()) if nql > 1 else 1
+
+
+def topk_edges_local(edges, edst, K, id_bits, q0, nql):
+    """Per-query top-K from edges that arrived from several scoring ranks (no useful order): re-base the
+    src field to this rank's id range, sort the whole (src, 1000 - milli, dst) key, cut.  edst: the dst
+    payload of key + payload edges, or None for packed ones."""
+    lib = _lib.load()
+    dev = edges.device
+    n = edges.numel()
+    if n == 0:
+        z = torch.empty((0,), dtype=torch.int32, device=dev)
+        return z, z.clone(), z.clone()
+    lb = local_bits_for(nql)
+    if lb + 11 + id_bits > 64:
+        raise NotImplementedError("%d local + %d global id bits do not fit the 64-bit top-K key" % (lb, id_bits))
+    loc = torch.empty_like(edges)
+    _lib.check(lib.qrlsh_edges_localize(_ptr(edges), _ptr(edst), n, id_bits, int(q0), int(nql), _ptr(loc), _stream()))
+    se, _ = sort_u64(loc, None, 0, lb + 11 + id_bits)
+    ws = _ws(lib.qrlsh_compact_workspace_bytes(n), dev)
+    total = torch.zeros(1, dtype=torch.int64, device=dev)
+    _lib.check(lib.qrlsh_topk_count(_ptr(se), n, K, id_bits, _ptr(ws), ws.numel(), _ptr(total), _stream()))
+    m = int(total.item())
+    src = torch.empty((m,), dtype=torch.int32, device=dev)
+    dst = torch.empty((m,), dtype=torch.int32, device=dev)
+    val = torch.empty((m,), dtype=torch.int32, device=dev)
+    _lib.check(lib.qrlsh_topk_fill_based(_ptr(se), None, n, K, id_bits, int(q0), _ptr(ws), _ptr(src), _ptr(dst),
+                                         _ptr(val), _stream()))
+    return src, dst, val
 
 
 def remap_pairs(pairs, q0, nql, need):

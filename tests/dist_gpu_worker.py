@@ -27,13 +27,19 @@ def main():
     else:
         dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    nql = nq // world
+    q0, n_real, nql = qdist.shard_range(nq, world, rank)
     K = pipeline.max_candidates(nq)
     perms = ops.legacy_permutations(P, D, seed=42)
     table = ops.perm_table(perms, dev)
-    off, rows = qrlsh.synth_csr(nq, D, seed=0, q0=rank * nql, nq_local=nql, device=dev)
+    off, rows = qrlsh.synth_csr(nq, D, seed=0, q0=q0, nq_local=n_real, device=dev)
     sig_mode = sys.argv[8] if len(sys.argv) > 8 else "auto"
-    res = qdist.query_similarities_sharded(off, rows, table, b, K, nq, exchange=mode, sig_exchange=sig_mode)
+    mean = float(sys.argv[9]) if len(sys.argv) > 9 else 16.0
+    if mean != 16.0:
+        off, rows = qrlsh.synth_csr(nq, D, seed=0, mean=mean, q0=q0, nq_local=n_real, device=dev)
+    phases = {}
+    res = qdist.query_similarities_sharded(off, rows, table, b, K, nq, exchange=mode, sig_exchange=sig_mode,
+                                           phases=phases)
+    assert phases["_steps"] == 1 and any(k.startswith("ms:") for k in phases)
     torch.cuda.synchronize()
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), pairs=res.pairs.cpu().numpy(), milli=res.milli.cpu().numpy(),
              src=res.src.cpu().numpy(), dst=res.dst.cpu().numpy(), val=res.val.cpu().numpy(),

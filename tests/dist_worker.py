@@ -70,78 +70,127 @@ class OracleBackend:
     def emit_pairs_chunked(self, recv, world, nb, nql, r):
         return self.emit_pairs(qdist._owned_bands(recv, world, nb, nql), r)
 
-    def sort_unique(self, words, bit_ranges):
+    def group_pairs_by_host(self, pairs, nql, world):
+        w = pairs.numpy().view(np.uint64)
+        h = pair_host(w, nql)
+        o = np.argsort(h, kind="stable")
+        bounds = np.searchsorted(h[o], np.arange(world + 1))
+        return _t(w[o].view(np.int64)), _t(bounds.astype(np.int64))
+
+    def sort_unique(self, words, ib):
         return _t(np.unique(words.numpy().view(np.uint64)).view(np.int64))
 
-    def sort_words(self, words, lo, hi):
-        w = words.numpy().view(np.uint64)
-        d = (w >> np.uint64(lo)) & np.uint64((1 << (hi - lo)) - 1)
-        return _t(w[np.argsort(d, kind="stable")].view(np.int64))
+    def remote_ids(self, pairs, q0, nql, nids, world):
+        p = pairs.numpy().view(np.uint64)
+        ends = np.concatenate([(p >> np.uint64(32)), (p & np.uint64(0xFFFFFFFF))]).astype(np.int64)
+        need = np.unique(ends[(ends < q0) | (ends >= q0 + nql)])
+        rid = type("Rid", (), {})()
+        rid.need, rid.q0, rid.nql = need, q0, nql
+        rid.bounds = _t(np.searchsorted(need, np.arange(world + 1) * nql).astype(np.int64))
+        return rid
+
+    def remote_id_list(self, rid, total):
+        assert total == len(rid.need)
+        return _t(rid.need)
+
+    def remap_pairs(self, pairs, rid):
+        p = pairs.numpy().view(np.uint64)
+        q0, nql = rid.q0, rid.nql
+
+        def slot(x):
+            x = x.astype(np.int64)
+            return np.where((x >= q0) & (x < q0 + nql), x - q0, nql + np.searchsorted(rid.need, x))
+        return _t(((slot(p >> np.uint64(32)) << 32) | slot(p & np.uint64(0xFFFFFFFF))).astype(np.int64))
+
+    def gather_rows(self, sig, norm2, ids, q0):
+        k = ids.numpy() - q0
+        return _t(sig.numpy()[k]), _t(norm2.numpy()[k])
+
+    def score(self, sig, norm2, sig_b, norm2_b, pairs):
+        rows = sig.numpy() if sig_b is None else np.concatenate([sig.numpy(), sig_b.numpy()])
+        return _t(O.score_pairs(np.ascontiguousarray(rows), pairs.numpy().view(np.uint64), mode=1))
 
     def verify_flags(self, sig_rows, b, pairs):
         """1 where the pair (two row indices of sig_rows) really shares a non-empty band"""
         p = pairs.numpy().view(np.uint64)
-        truth = O.candidates_from_sig(np.ascontiguousarray(sig_rows.numpy()), b)
-        return _t(np.isin(p, truth).astype(np.uint8))
+        sr = np.ascontiguousarray(sig_rows.numpy())
+        lo = np.minimum(p >> np.uint64(32), p & np.uint64(0xFFFFFFFF))
+        hi = np.maximum(p >> np.uint64(32), p & np.uint64(0xFFFFFFFF))
+        truth = O.candidates_from_sig(sr, b)
+        return _t(np.isin((lo << np.uint64(32)) | hi, truth).astype(np.uint8))
 
-    def remap_pairs(self, pairs, q0, nql, need):
-        p = pairs.numpy().view(np.uint64)
-        i, j = (p >> np.uint64(32)).astype(np.int64), (p & np.uint64(0xFFFFFFFF)).astype(np.int64)
-        local = (j >= q0) & (j < q0 + nql)
-        slot = np.where(local, j - q0, nql + np.searchsorted(need.numpy(), j))
-        return _t((((i - q0) << 32) | slot).astype(np.int64))
-
-    def pair_edges(self, pairs, milli, id_bits, wide):
+    def edges(self, pairs, milli, ib, wide):
         p = pairs.numpy().view(np.uint64)
         i, j = p >> np.uint64(32), p & np.uint64(0xFFFFFFFF)
         inv = (1000 - milli.numpy()).astype(np.uint64)
+        n = len(p)
+        k = np.empty(2 * n, dtype=np.uint64)
         if wide:
-            return ((_t(((i << np.uint64(11)) | inv).view(np.int64)), _t(j.astype(np.int32))),
-                    (_t(((j << np.uint64(11)) | inv).view(np.int64)), _t(i.astype(np.int32))))
-        sh, ib = np.uint64(id_bits + 11), np.uint64(id_bits)
-        return _t(((i << sh) | (inv << ib) | j).view(np.int64)), _t(((j << sh) | (inv << ib) | i).view(np.int64))
+            d = np.empty(2 * n, dtype=np.int32)
+            k[0::2], k[1::2] = (i << np.uint64(11)) | inv, (j << np.uint64(11)) | inv
+            d[0::2], d[1::2] = j.astype(np.int32), i.astype(np.int32)
+            return _t(k.view(np.int64)), _t(d)
+        sh, b_ = np.uint64(ib + 11), np.uint64(ib)
+        k[0::2], k[1::2] = (i << sh) | (inv << b_) | j, (j << sh) | (inv << b_) | i
+        return _t(k.view(np.int64)), None
 
-    def score_only(self, sig_rows, norm_rows, pairs):
-        return _t(O.score_pairs(np.ascontiguousarray(sig_rows.numpy()), pairs.numpy().view(np.uint64), mode=1))
-
-    def owner_sizes(self, words, lo, shard, world):
-        w = words.numpy().view(np.uint64)
-        return np.bincount(((w >> np.uint64(lo)) // np.uint64(shard)).astype(np.int64), minlength=world)[:world].tolist()
-
-    def group_by_owner(self, words, lo, shard, vals=None):
-        w = words.numpy().view(np.uint64)
-        o = np.argsort((w >> np.uint64(lo)) // np.uint64(shard), kind="stable")
-        return _t(w[o].view(np.int64)), (_t(vals.numpy()[o]) if vals is not None else None)
-
-    def sort_words_kv(self, words, vals, lo, hi):
-        w = words.numpy().view(np.uint64)
-        d = (w >> np.uint64(lo)) & np.uint64((1 << (hi - lo)) - 1)
-        o = np.argsort(d, kind="stable")
-        return _t(w[o].view(np.int64)), _t(vals.numpy()[o])
+    def group_edges_by_owner(self, keys, dst, lo, nql, world):
+        w = keys.numpy().view(np.uint64)
+        own = ((w >> np.uint64(lo)) // np.uint64(nql)).astype(np.int64)
+        o = np.argsort(own, kind="stable")
+        bounds = np.searchsorted(own[o], np.arange(world + 1))
+        return _t(w[o].view(np.int64)), (_t(dst.numpy()[o]) if dst is not None else None), _t(bounds.astype(np.int64))
 
     def topk(self, edges, K, id_bits):
-        if isinstance(edges, tuple):                       # wide ids: (src << 11 | inv, dst), input order = dst asc per src
-            k = edges[0].numpy().view(np.uint64)
-            dd = edges[1].numpy()
-            o = np.argsort(k, kind="stable")
-            k, dd = k[o], dd[o]
-            src = (k >> np.uint64(11)).astype(np.int64)
-            keep = np.ones(len(k), dtype=bool)
-            if len(k) > K:
-                keep[K:] = src[K:] != src[:-K]
-            k, dd = k[keep], dd[keep]
-            return (_t((k >> np.uint64(11)).astype(np.int32)), _t(dd.astype(np.int32)),
-                    _t((1000 - (k & np.uint64(0x7FF)).astype(np.int64)).astype(np.int32)))
-        e = np.sort(edges.numpy().view(np.uint64))
-        src = (e >> np.uint64(id_bits + 11)).astype(np.int64)
-        keep = np.ones(len(e), dtype=bool)
-        if len(e) > K:
+        """edges in pair order (one scoring rank): the stable (src, value) order of the one-GPU path"""
+        if isinstance(edges, tuple):
+            k, dd = edges[0].numpy().view(np.uint64), edges[1].numpy()
+            src, inv = (k >> np.uint64(11)).astype(np.int64), (k & np.uint64(0x7FF)).astype(np.int64)
+        else:
+            k = edges.numpy().view(np.uint64)
+            src = (k >> np.uint64(id_bits + 11)).astype(np.int64)
+            inv = ((k >> np.uint64(id_bits)) & np.uint64(0x7FF)).astype(np.int64)
+            dd = (k & np.uint64((1 << id_bits) - 1)).astype(np.int64)
+        return self._cut(src, inv, np.asarray(dd, dtype=np.int64), K, stable_only=True)
+
+    def topk_local(self, keys, dst, K, ib, q0, nql):
+        k = keys.numpy().view(np.uint64)
+        if dst is not None:
+            src, inv = (k >> np.uint64(11)).astype(np.int64), (k & np.uint64(0x7FF)).astype(np.int64)
+            dd = dst.numpy().astype(np.int64)
+        else:
+            src = (k >> np.uint64(ib + 11)).astype(np.int64)
+            inv = ((k >> np.uint64(ib)) & np.uint64(0x7FF)).astype(np.int64)
+            dd = (k & np.uint64((1 << ib) - 1)).astype(np.int64)
+        assert len(src) == 0 or (src.min() >= q0 and src.max() < q0 + nql)
+        return self._cut(src, inv, dd, K, stable_only=False)
+
+    @staticmethod
+    def _cut(src, inv, dd, K, stable_only):
+        # stable_only: order by (src, inv) alone and rely on the arrival order for dst (what the device does
+        # when a single rank scored everything); otherwise the whole (src, inv, dst) key
+        o = np.lexsort((inv, src)) if stable_only else np.lexsort((dd, inv, src))
+        src, inv, dd = src[o], inv[o], dd[o]
+        keep = np.ones(len(src), dtype=bool)
+        if len(src) > K:
             keep[K:] = src[K:] != src[:-K]
-        e = e[keep]
-        src = (e >> np.uint64(id_bits + 11)).astype(np.int32)
-        dst = (e & np.uint64((1 << id_bits) - 1)).astype(np.int32)
-        val = (1000 - ((e >> np.uint64(id_bits)) & np.uint64(0x7FF)).astype(np.int64)).astype(np.int32)
-        return _t(src), _t(dst), _t(val)
+        return _t(src[keep].astype(np.int32)), _t(dd[keep].astype(np.int32)), _t((1000 - inv[keep]).astype(np.int32))
+
+
+def mix64(z):
+    z = z.astype(np.uint64)
+    with np.errstate(over="ignore"):
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def pair_host(pairs, nql):
+    """numpy twin of csrc/common.h:qr_pair_host -- the rank that scores pair i << 32 | j"""
+    pairs = np.asarray(pairs, dtype=np.uint64)
+    pick_j = (mix64(pairs) >> np.uint64(63)).astype(bool)
+    ids = np.where(pick_j, pairs & np.uint64(0xFFFFFFFF), pairs >> np.uint64(32))
+    return (ids // np.uint64(nql)).astype(np.int64)
 
 
 def main():
@@ -151,10 +200,10 @@ def main():
     sig_mode = ([e[4:] for e in extra if e.startswith("sig=")] or ["auto"])[0]
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    nql = nq // world
+    q0, n_real, nql = qdist.shard_range(nq, world, rank)
     K = O.max_candidates(nq)
     perms = O.legacy_permutations(42, P, D)
-    off, rows = O.synth_csr(nq, D, seed=3, cluster=4, mean=6.0, q0=rank * nql, nq_local=nql)
+    off, rows = O.synth_csr(nq, D, seed=3, cluster=4, mean=6.0, q0=q0, nq_local=n_real)
     res = qdist.query_similarities_sharded(_t(off), _t(rows), OracleTable(perms), b, K, nq, exchange=mode,
                                            backend=OracleBackend(), wide_ids=wide or None, sig_exchange=sig_mode)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), sig=res.sig.numpy(), pairs=res.pairs.numpy(),

@@ -12,6 +12,7 @@ import pytest
 from oracle import oracle as O
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def _run(tmp_path, world, nq, D, P, b, mode, port, extra=()):
@@ -25,16 +26,18 @@ def _run(tmp_path, world, nq, D, P, b, mode, port, extra=()):
     return [np.load(os.path.join(tmp_path, "rank%d.npz" % r)) for r in range(world)]
 
 
-@pytest.mark.parametrize("world,mode,b,extra", [(2, "all_to_all", 8, ()), (2, "all_gather", 8, ("sig=fetch",)),
-                                               (3, "all_to_all", 8, ("sig=fetch",)),
-                                               (3, "all_to_all", 8, ("sig=all_gather",)),
-                                               (2, "all_to_all", 4, ("wide", "sig=fetch")),
-                                               (2, "all_to_all", 4, ("wide", "sig=all_gather"))])
-def test_sharded_equals_single_process(tmp_path, world, mode, b, extra):
+@pytest.mark.parametrize("world,mode,b,extra,nq", [(2, "all_to_all", 8, (), 600), (2, "all_gather", 8, ("sig=fetch",), 600),
+                                                  (3, "all_to_all", 8, ("sig=fetch",), 600),
+                                                  (3, "all_to_all", 8, ("sig=all_gather",), 601),   # 601 = 3 * 201 - 2:
+                                                  (3, "all_to_all", 8, ("sig=fetch",), 601),        # padded last shard
+                                                  (4, "all_gather", 8, ("sig=fetch",), 598),
+                                                  (2, "all_to_all", 4, ("wide", "sig=fetch"), 600),
+                                                  (2, "all_to_all", 4, ("wide", "sig=all_gather"), 599)])
+def test_sharded_equals_single_process(tmp_path, world, mode, b, extra, nq):
     # b = 4 with P = 32 is a wide band (r = 8: hashed bucket ids + verification); "wide" forces the
     # key + payload edge format used when two ids + 11 score bits do not fit 64 bits
-    nq, D, P = 600, 512, 32
-    port = 29531 + world + (0 if mode == "all_to_all" else 7) + len(extra) * 11 + sum(map(len, extra))
+    D, P = 512, 32
+    port = 29531 + world + (0 if mode == "all_to_all" else 7) + len(extra) * 11 + sum(map(len, extra)) + nq % 7 * 13
     outs = _run(tmp_path, world, nq, D, P, b, mode, port, extra)
     for o in outs:     # the signature exchange that was asked for is the one that ran ("auto": either)
         want = [e[4:] for e in extra if e.startswith("sig=")]
@@ -43,21 +46,43 @@ def test_sharded_equals_single_process(tmp_path, world, mode, b, extra):
     K = O.max_candidates(nq)
     off, rows = O.synth_csr(nq, D, seed=3, cluster=4, mean=6.0)
     ref = O.query_similarities(off, rows, D, P, b, K, 42)
-    assert np.array_equal(np.concatenate([o["sig"] for o in outs]), ref["sig"])
+    assert np.array_equal(np.concatenate([o["sig"] for o in outs]), ref["sig"])       # pad rows are not returned
+    # candidate pairs: every rank holds the sorted share it scored; the shares are disjoint and their union is
+    # the single-process list
     pairs = np.concatenate([o["pairs"] for o in outs]).view(np.uint64)
-    assert np.array_equal(pairs, ref["pairs"])                     # rank order == global order, no duplicates
-    assert np.array_equal(np.concatenate([o["milli"] for o in outs]), ref["milli"])
+    milli = np.concatenate([o["milli"] for o in outs])
+    order = np.argsort(pairs, kind="stable")
+    assert np.array_equal(pairs[order], ref["pairs"])                # nothing missing, nothing twice
+    assert np.array_equal(milli[order], ref["milli"])
     assert np.array_equal(np.concatenate([o["src"] for o in outs]), ref["src"])
     assert np.array_equal(np.concatenate([o["dst"] for o in outs]), ref["dst"])
     assert np.array_equal(np.concatenate([o["val"] for o in outs]), ref["val"])
     if P // b <= 4:
         keys = O.band_keys(ref["sig"], b)
         assert sum(int(o["emitted"]) for o in outs) == O.emitted_pairs(keys, P // b)
-    nql = nq // world
-    for r, o in enumerate(outs):                                   # ownership: i (and src) in the rank's range
-        i = o["pairs"].view(np.uint64) >> np.uint64(32)
-        assert len(i) == 0 or (i.min() >= r * nql and i.max() < (r + 1) * nql)
-        assert len(o["src"]) == 0 or (o["src"].min() >= r * nql and o["src"].max() < (r + 1) * nql)
+    nql = -(-nq // world)
+    from dist_worker import pair_host
+    sizes = []
+    for r, o in enumerate(outs):
+        p = o["pairs"].view(np.uint64)
+        assert np.all(p[1:] > p[:-1])                                # sorted unique share
+        assert np.all(pair_host(p, nql) == r)                        # scored where qr_pair_host says
+        sizes.append(len(p))
+        assert len(o["src"]) == 0 or (o["src"].min() >= r * nql and o["src"].max() < min((r + 1) * nql, nq))
+    assert max(sizes) <= 2.0 * sum(sizes) / world + 16               # the coin splits the pairs about evenly
+
+
+def test_shard_ranges_tile_the_queries():
+    import qrlsh.dist as qd
+    for nq in (1, 7, 600, 601, 10_000_000):
+        for w in (1, 2, 3, 4, 8):
+            nxt = 0
+            for g in range(w):
+                q0, n, nql = qd.shard_range(nq, w, g)
+                assert nql == -(-nq // w) and 0 <= n <= nql
+                assert q0 == nxt or n == 0
+                nxt = q0 + n
+            assert nxt == nq
 
 
 def test_band_owner_ranges_cover_all_bands():

@@ -420,8 +420,124 @@ def test_full_size_config2_properties_and_oracle():
     assert np.array_equal(res.milli.cpu().numpy(), O.score_pairs(sig, opairs, mode=1))
 
 
+def _check_properties(res, nq, K):
+    """size-independent properties of a hot-path result; -> (pairs u64, src, dst, val) host arrays"""
+    pairs = u64(res.pairs)
+    i, j = (pairs >> np.uint64(32)).astype(np.int64), (pairs & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    assert np.all(i < j) and j.max() < nq
+    assert np.all(pairs[1:] > pairs[:-1])                       # sorted, unique
+    src, dst, val = res.src.cpu().numpy(), res.dst.cpu().numpy(), res.val.cpu().numpy()
+    same = src[1:] == src[:-1]                                  # (src, value desc, dst asc), no repeats
+    assert np.all((src[1:] > src[:-1]) | (same & ((val[1:] < val[:-1]) | ((val[1:] == val[:-1]) & (dst[1:] > dst[:-1])))))
+    assert np.bincount(src).max() <= K
+    assert val.min() >= -1000 and val.max() <= 1000
+    ek = (np.minimum(src, dst).astype(np.uint64) << np.uint64(32)) | np.maximum(src, dst).astype(np.uint64)
+    assert np.all(np.isin(ek[::997], pairs))                    # kept edges are candidate pairs
+    return pairs, src, dst, val
+
+
+def _check_against_oracle(res, off, rows, perms, b, K, nq):
+    pairs, src, dst, val = _check_properties(res, nq, K)
+    P = perms.shape[0]
+    sig = O.minhash(off.cpu().numpy(), rows.cpu().numpy(), perms)
+    assert np.array_equal(res.sig_int32().cpu().numpy(), sig)
+    opairs = O.candidates(O.band_keys(sig, b), P // b)
+    assert np.array_equal(pairs, opairs)
+    milli = O.score_pairs(sig, opairs, mode=1)
+    assert np.array_equal(res.milli.cpu().numpy(), milli)
+    s, d, v = O.topk(opairs, milli, K)
+    assert np.array_equal(src, s) and np.array_equal(dst, d) and np.array_equal(val, v)
+
+
+def test_full_size_config3_equals_oracle():
+    """BASELINE configs[2] = SURVEY config 3 (10 M queries, P=128, b=32, one GPU): the workload bench.py
+    times.  Two-step partition (T = 12), long rows through the one-row-per-workgroup kernel; signatures,
+    candidate pairs, scores and top-K are compared exactly with the oracle (16 s on the box's host cores)."""
+    nq, D, P, b = 10_000_000, 32768, 128, 32
+    K = pipeline.max_candidates(nq)
+    assert K == 40
+    off, rows = qrlsh.synth_csr(nq, D, seed=0, device=DEV)
+    perms = ops.legacy_permutations(P, D, seed=42)
+    res = pipeline.query_similarities(off, rows, ops.perm_table(perms, DEV), b, K)
+    torch.cuda.synchronize()
+    assert res.stats["bucket_path"] == "partition+lds" and res.stats["dedup_path"] == "rows-in-lds"
+    assert res.stats["part_bits"] == 12
+    O.set_threads(16)
+    _check_against_oracle(res, off, rows, perms, b, K, nq)
+    del res
+    torch.cuda.empty_cache()
+
+
+def test_full_size_256_perm_64_bands_equals_oracle():
+    """the config-4/5 shape (P=256, b=64) at 1 M queries, exact against the oracle"""
+    nq, D, P, b = 1_000_000, 32768, 256, 64
+    K = pipeline.max_candidates(nq)
+    off, rows = qrlsh.synth_csr(nq, D, seed=0, device=DEV)
+    perms = ops.legacy_permutations(P, D, seed=42)
+    res = pipeline.query_similarities(off, rows, ops.perm_table(perms, DEV), b, K)
+    torch.cuda.synchronize()
+    O.set_threads(16)
+    _check_against_oracle(res, off, rows, perms, b, K, nq)
+
+
+def test_more_than_2_pow_24_queries_equals_oracle():
+    """nq > 2^24 (the per-rank record count of configs 4-5): ids no longer fit the 24 bits the partition
+    kernel packs beside the part number (BIGID variant of part_scatter_atomic_kernel), T = 12; tiny P / b
+    keep it cheap.  Also drives the count-then-fill API, whose sort-based partition takes its non-staged
+    scatter for nq > 2^24 (sort.hip: bucket_partition), and the plain-layout size rules."""
+    nq, D, P, b = 17_000_000, 32768, 8, 2
+    assert nq > (1 << 24)
+    K = pipeline.max_candidates(nq)
+    off, rows = qrlsh.synth_csr(nq, D, seed=0, device=DEV)
+    perms = ops.legacy_permutations(P, D, seed=42)
+    table = ops.perm_table(perms, DEV)
+    res = pipeline.query_similarities(off, rows, table, b, K)
+    torch.cuda.synchronize()
+    assert res.stats["bucket_path"] == "partition+lds"
+    O.set_threads(16)
+    _check_against_oracle(res, off, rows, perms, b, K, nq)
+    # count-then-fill API on the same keys: the sort-based partition, non-staged for nq > 2^24
+    _, _, keys = ops.minhash(off, rows, table, b=b, compact=True)
+    slow = ops.emit_pairs_fast(keys, P // b, one_pass=False)
+    assert slow is not None and slow.numel() == res.stats["emitted_pairs"]
+    assert np.array_equal(u64(ops.unique_pairs(slow, nq)), u64(res.pairs))
+    # keys as a band-partitioned all-to-all delivers them, read in place at nq > 2^24
+    world = 4
+    nql = nq // world
+    recv = keys.view(b, world, nql).permute(1, 0, 2).contiguous()
+    chunked = ops.emit_pairs_fast(recv.view(-1), P // b, chunks=(world, b, nql))
+    assert chunked is not None and chunked.numel() == slow.numel()
+    assert np.array_equal(u64(ops.unique_pairs(chunked, nq)), u64(res.pairs))
+
+
+def test_wide_ids_beyond_2_pow_26_queries():
+    """nq > 2^26: two ids + 11 score bits do not fit one 64-bit top-K key, the key + payload edge format
+    is selected by the size itself (not forced).  One band of four permutations keeps the work small;
+    checked through size-independent properties and, exactly, against the oracle's candidate / score /
+    top-K stages fed with the device's own (already verified kernel) signatures."""
+    nq, D, P, b = 68_000_000, 32768, 4, 1
+    assert ops.wide_ids(ops.id_bits_for(nq))
+    K = pipeline.max_candidates(nq)
+    off, rows = qrlsh.synth_csr(nq, D, seed=0, mean=4.0, device=DEV)
+    perms = ops.legacy_permutations(P, D, seed=42)
+    res = pipeline.query_similarities(off, rows, ops.perm_table(perms, DEV), b, K)
+    torch.cuda.synchronize()
+    pairs, src, dst, val = _check_properties(res, nq, K)
+    sig = res.sig_int32().cpu().numpy()
+    n_chk = 2_000_000                                             # signatures: first 2 M queries against the oracle
+    ho = off[: n_chk + 1].cpu().numpy()
+    assert np.array_equal(sig[:n_chk], O.minhash(ho, rows[: int(ho[-1])].cpu().numpy(), perms))
+    O.set_threads(16)
+    opairs = O.candidates(O.band_keys(sig, b), P // b)
+    assert np.array_equal(pairs, opairs)
+    milli = O.score_pairs(sig, opairs, mode=1)
+    assert np.array_equal(res.milli.cpu().numpy(), milli)
+    s, d, v = O.topk(opairs, milli, K)
+    assert np.array_equal(src, s) and np.array_equal(dst, d) and np.array_equal(val, v)
+
+
 # ---------------------------------------------------------------------------- sharded driver
-def _run_dist_gpu(tmp_path, world, nq, D, P, b, mode, backend, port, sig_mode="auto"):
+def _run_dist_gpu(tmp_path, world, nq, D, P, b, mode, backend, port, sig_mode="auto", mean=16.0):
     import subprocess
     import sys as _sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -430,58 +546,132 @@ def _run_dist_gpu(tmp_path, world, nq, D, P, b, mode, backend, port, sig_mode="a
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     cmd = [_sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "tests", "dist_gpu_worker.py"),
-           str(tmp_path), str(nq), str(D), str(P), str(b), mode, backend, sig_mode]
+           str(tmp_path), str(nq), str(D), str(P), str(b), mode, backend, sig_mode, str(mean)]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     return [np.load(os.path.join(tmp_path, "rank%d.npz" % r)) for r in range(world)]
 
 
-@pytest.mark.parametrize("world,mode,backend,sig_mode", [(1, "all_to_all", "nccl", "auto"),
-                                                         (2, "all_to_all", "gloo", "auto"),
-                                                         (4, "all_gather", "gloo", "fetch"),
-                                                         (2, "all_to_all", "gloo", "all_gather")])
-def test_sharded_driver_on_gpu_equals_single_gpu(tmp_path, world, mode, backend, sig_mode):
-    nq, D, P, b = 40000, 32768, 128, 32
-    outs = _run_dist_gpu(tmp_path, world, nq, D, P, b, mode, backend, 29571 + world + len(sig_mode), sig_mode)
-    for o in outs:
-        if sig_mode != "auto":
-            assert str(o["sig_exchange"]) == sig_mode
-        if world > 1 and str(o["sig_exchange"]) == "fetch":
-            assert 0 <= int(o["fetched"]) <= (world - 1) * (nq // world)   # only rows of the other shards, each once
-    K = pipeline.max_candidates(nq)
-    off, rows = qrlsh.synth_csr(nq, D, seed=0, device=DEV)
-    res = pipeline.query_similarities(off, rows, ops.perm_table(ops.legacy_permutations(P, D, seed=42), DEV), b, K)
-    torch.cuda.synchronize()
-    assert np.array_equal(np.concatenate([o["pairs"] for o in outs]), res.pairs.cpu().numpy())
-    assert np.array_equal(np.concatenate([o["milli"] for o in outs]), res.milli.cpu().numpy())
+def _check_sharded_against(outs, res, nq, world):
+    """the ranks' outputs against a single-GPU HotPathResult of the same queries"""
+    from dist_worker import pair_host
+    nql = -(-nq // world)
+    pairs = np.concatenate([o["pairs"] for o in outs]).view(np.uint64)
+    milli = np.concatenate([o["milli"] for o in outs])
+    order = np.argsort(pairs, kind="stable")
+    assert np.array_equal(pairs[order], u64(res.pairs))            # disjoint shares, union = the single-GPU list
+    assert np.array_equal(milli[order], res.milli.cpu().numpy())
+    for r, o in enumerate(outs):
+        p = o["pairs"].view(np.uint64)
+        assert np.all(p[1:] > p[:-1]) and np.all(pair_host(p, nql) == r)
     assert np.array_equal(np.concatenate([o["src"] for o in outs]), res.src.cpu().numpy())
     assert np.array_equal(np.concatenate([o["dst"] for o in outs]), res.dst.cpu().numpy())
     assert np.array_equal(np.concatenate([o["val"] for o in outs]), res.val.cpu().numpy())
     assert sum(int(o["emitted"]) for o in outs) == res.stats["emitted_pairs"]
 
 
+@pytest.mark.parametrize("world,mode,backend,sig_mode,nq", [(1, "all_to_all", "nccl", "auto", 40000),
+                                                            (2, "all_to_all", "gloo", "auto", 40000),
+                                                            (4, "all_gather", "gloo", "fetch", 40000),
+                                                            (3, "all_to_all", "gloo", "fetch", 40001),   # padded last shard
+                                                            (2, "all_to_all", "gloo", "all_gather", 39999)])
+def test_sharded_driver_on_gpu_equals_single_gpu(tmp_path, world, mode, backend, sig_mode, nq):
+    D, P, b = 32768, 128, 32
+    outs = _run_dist_gpu(tmp_path, world, nq, D, P, b, mode, backend, 29571 + world + len(sig_mode) + nq % 5, sig_mode)
+    nql = -(-nq // world)
+    for o in outs:
+        if sig_mode != "auto":
+            assert str(o["sig_exchange"]) == sig_mode
+        if world > 1 and str(o["sig_exchange"]) == "fetch":
+            assert 0 <= int(o["fetched"]) <= (world - 1) * nql   # only rows of the other shards, each once
+    K = pipeline.max_candidates(nq)
+    off, rows = qrlsh.synth_csr(nq, D, seed=0, device=DEV)
+    res = pipeline.query_similarities(off, rows, ops.perm_table(ops.legacy_permutations(P, D, seed=42), DEV), b, K)
+    torch.cuda.synchronize()
+    _check_sharded_against(outs, res, nq, world)
+
+
+def test_sharded_driver_wide_ids_beyond_2_pow_26(tmp_path):
+    """config-5-sized id space through the SHARDED driver on the device: nq_total > 2^26 (key + payload
+    edges, re-based to 64-bit local keys on arrival), more than 2^24 records per owned band (BIGID
+    partition reading the exchanged key layout in place), two gloo ranks sharing the GPU."""
+    nq, D, P, b, world = 68_000_000, 32768, 4, 2, 2
+    outs = _run_dist_gpu(tmp_path, world, nq, D, P, b, "all_to_all", "gloo", 29597, "fetch", mean=4.0)
+    K = pipeline.max_candidates(nq)
+    off, rows = qrlsh.synth_csr(nq, D, seed=0, mean=4.0, device=DEV)
+    res = pipeline.query_similarities(off, rows, ops.perm_table(ops.legacy_permutations(P, D, seed=42), DEV), b, K)
+    torch.cuda.synchronize()
+    assert ops.wide_ids(ops.id_bits_for(nq))
+    _check_sharded_against(outs, res, nq, world)
+
+
 def test_multi_gpu_glue_kernels_match_numpy():
+    from dist_worker import pair_host
     rng = np.random.default_rng(3)
-    nq, q0, nql, n = 100000, 30000, 20000, 50000
-    i = rng.integers(q0, q0 + nql, size=n).astype(np.uint64)
-    j = rng.integers(0, nq, size=n).astype(np.uint64)
+    nq, q0, nql, n, world = 100000, 40000, 20000, 50000, 5
+    a = rng.integers(q0, q0 + nql, size=n).astype(np.uint64)          # one endpoint local ...
+    c = rng.integers(0, nq, size=n).astype(np.uint64)                 # ... the other anywhere
+    c[c == a] += np.uint64(1)
+    i, j = np.minimum(a, c), np.maximum(a, c)
     pairs = (i << np.uint64(32)) | j
-    remote = (j < q0) | (j >= q0 + nql)
-    need = np.unique(j[remote]).astype(np.int64)
-    got = u64(ops.remap_pairs(dev(pairs.view(np.int64)), q0, nql, dev(need)))
-    slot = np.where(remote, nql + np.searchsorted(need, j.astype(np.int64)), j.astype(np.int64) - q0).astype(np.uint64)
-    assert np.array_equal(got, ((i - np.uint64(q0)) << np.uint64(32)) | slot)
-    assert np.array_equal(u64(ops.remap_pairs(dev(pairs[~remote].view(np.int64)), q0, nql, dev(need[:0]))),
-                          ((i[~remote] - np.uint64(q0)) << np.uint64(32)) | (j[~remote] - np.uint64(q0)))
+    # scoring rank of a pair: one pass that groups by it + the split points
+    g, _ = ops.sort_u64(dev(pairs.view(np.int64)), None, host_shard=nql)
+    host = pair_host(pairs, nql)
+    order = np.argsort(host, kind="stable")
+    assert np.array_equal(u64(g), pairs[order])
+    assert np.array_equal(ops.owner_bounds(g, -1, nql, world).cpu().numpy(), np.searchsorted(host[order], np.arange(world + 1)))
+    assert 0.4 < np.mean(host == (i // np.uint64(nql)).astype(np.int64)) < 0.9    # a coin, not "always the smaller id"
+    # remote id set, request list, re-indexed pairs
+    ends = np.concatenate([i, j]).astype(np.int64)
+    need = np.unique(ends[(ends < q0) | (ends >= q0 + nql)])
+    rid = ops.remote_ids(dev(pairs.view(np.int64)), q0, nql, nq, world)
+    assert np.array_equal(rid.bounds.cpu().numpy(), np.searchsorted(need, np.arange(world + 1) * nql))
+    assert np.array_equal(ops.remote_id_list(rid, len(need)).cpu().numpy(), need)
+
+    def slot(x):
+        x = x.astype(np.int64)
+        return np.where((x >= q0) & (x < q0 + nql), x - q0, nql + np.searchsorted(need, x)).astype(np.uint64)
+    local = u64(ops.remap_pairs_ids(dev(pairs.view(np.int64)), rid))
+    assert np.array_equal(local, (slot(i) << np.uint64(32)) | slot(j))
+    rid0 = ops.remote_ids(dev(pairs[:0].view(np.int64)), q0, nql, nq + 7, world)        # no pairs, nids % 32 != 0
+    assert not rid0.bounds.cpu().numpy().any()
+    # rows on request, and scoring against the two-piece table == scoring against the whole one
+    P = 24
+    sig = rng.integers(-1, 30000, size=(nq, P)).astype(np.int32)
+    norm = (sig.astype(np.int64) ** 2).sum(1)
+    for sg in (dev(sig), dev(np.where(sig < 0, 0xFFFF, sig).astype(np.uint16).view(np.int16))):
+        rows_b, norms_b = ops.gather_rows(sg, dev(norm), dev(need), 0)
+        assert np.array_equal(rows_b.cpu().numpy(), sg.cpu().numpy()[need]) and np.array_equal(norms_b.cpu().numpy(), norm[need])
+        whole = ops.score_pairs(sg, dev(norm), dev(pairs.view(np.int64)))[0]
+        split = ops.score_pairs_split(sg[q0:q0 + nql].contiguous(), dev(norm[q0:q0 + nql]), rows_b, norms_b, dev(local.view(np.int64)))
+        assert np.array_equal(split.cpu().numpy(), whole.cpu().numpy())
+    # edges: interleaved, packed and key + payload; re-based at the owner
     milli = rng.integers(0, 1001, size=n).astype(np.int32)
     inv = (1000 - milli).astype(np.uint64)
     ib = 17
+    e = u64(ops.pair_edges_interleaved(dev(pairs.view(np.int64)), dev(milli), ib))
+    assert np.array_equal(e[0::2], (i << np.uint64(ib + 11)) | (inv << np.uint64(ib)) | j)
+    assert np.array_equal(e[1::2], (j << np.uint64(ib + 11)) | (inv << np.uint64(ib)) | i)
+    ek, ed = ops.pair_edges_interleaved(dev(pairs.view(np.int64)), dev(milli), ib, wide=True)
+    assert np.array_equal(u64(ek)[0::2], (i << np.uint64(11)) | inv) and np.array_equal(ed.cpu().numpy()[1::2], i.astype(np.int32))
     fwd, rev = ops.pair_edges(dev(pairs.view(np.int64)), dev(milli), ib)
-    assert np.array_equal(u64(fwd), (i << np.uint64(ib + 11)) | (inv << np.uint64(ib)) | j)
-    assert np.array_equal(u64(rev), (j << np.uint64(ib + 11)) | (inv << np.uint64(ib)) | i)
-    (fk, fd), (rk, rd) = ops.pair_edges(dev(pairs.view(np.int64)), dev(milli), ib, wide=True)
-    assert np.array_equal(u64(fk), (i << np.uint64(11)) | inv) and np.array_equal(fd.cpu().numpy(), j.astype(np.int32))
-    assert np.array_equal(u64(rk), (j << np.uint64(11)) | inv) and np.array_equal(rd.cpu().numpy(), i.astype(np.int32))
+    assert np.array_equal(u64(fwd), e[0::2]) and np.array_equal(u64(rev), e[1::2])
+    # top-K at the owner from edges in arbitrary order == the one-GPU top-K restricted to its queries
+    K = 5
+    s0, d0, v0 = ops.topk_edges(dev(e.view(np.int64)), K, ib)           # pair order is NOT sorted here: sort first
+    sp = np.sort(pairs)
+    o2 = np.argsort(pairs, kind="stable")
+    e_sorted = u64(ops.pair_edges_interleaved(dev(sp.view(np.int64)), dev(milli[o2]), ib))
+    s0, d0, v0 = (t.cpu().numpy() for t in ops.topk_edges(dev(e_sorted.view(np.int64)), K, ib))
+    mine = (e >> np.uint64(ib + 11) >= np.uint64(q0)) & (e >> np.uint64(ib + 11) < np.uint64(q0 + nql))
+    shuffled = e[mine][rng.permutation(int(mine.sum()))]
+    s1, d1, v1 = (t.cpu().numpy() for t in ops.topk_edges_local(dev(shuffled.view(np.int64)), None, K, ib, q0, nql))
+    sel = (s0 >= q0) & (s0 < q0 + nql)
+    assert np.array_equal(s1, s0[sel]) and np.array_equal(d1, d0[sel]) and np.array_equal(v1, v0[sel])
+    wk, wd = u64(ek)[mine], ed.cpu().numpy()[mine]
+    perm = rng.permutation(len(wk))
+    s2, d2, v2 = (t.cpu().numpy() for t in ops.topk_edges_local(dev(wk[perm].view(np.int64)), dev(wd[perm]), K, ib, q0, nql))
+    assert np.array_equal(s2, s1) and np.array_equal(d2, d1) and np.array_equal(v2, v1)
 
 
 # ---------------------------------------------------------------------------- fast bucket path

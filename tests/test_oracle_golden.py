@@ -142,3 +142,19 @@ def test_user_similarity_and_prediction_loop_match_reference(sub):
     # numba's sequential np.sum (the real reference) and numpy's pairwise order agree here
     seq = O.predict_scores(g["ratings"], qs, us, summation=lambda a: float(sum(float(x) for x in a)))
     assert np.array_equal(seq, g["final"])
+
+
+@pytest.mark.parametrize("nq,D", [(1_000_000, 32768), (300_000, 100_000)])
+def test_sklearn_order_and_exact_integer_scoring_agree_at_scale(nq, D):
+    """a5 (recommender.py:203-204) at full config-2 size: the sklearn-order arithmetic (mode 0:
+    normalise each row in float64, then dot) and the exact-integer form the HIP kernel computes
+    (mode 1: int64 dot / (sqrt(na) * sqrt(nb))) must round to the same milli on EVERY candidate
+    pair -- a flip at a x.xxx5 boundary would be a real parity finding for score.hip."""
+    P, b = 128, 32
+    off, rows = O.synth_csr(nq, D, seed=0)
+    sig = O.minhash(off, rows, O.legacy_permutations(42, P, D))
+    pairs = O.candidates(O.band_keys(sig, b), P // b)
+    assert len(pairs) > 2 * nq
+    m0 = O.score_pairs(sig, pairs, mode=0)
+    m1 = O.score_pairs(sig, pairs, mode=1)
+    assert np.array_equal(m0, m1), "%d of %d pairs round differently" % (int((m0 != m1).sum()), len(pairs))
