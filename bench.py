@@ -11,9 +11,10 @@ Workload (BASELINE.json):
   N > 1 : configs[3] -- the SAME 10 M queries sharded N ways (strong scaling, SURVEY 8e: efficiency =
           T1 / (N * TN) on identical total work): rank g owns ceil(nq/N) consecutive query ids,
           signatures are computed per shard, bucket ids are exchanged over RCCL (band-partitioned
-          all-to-all by default, --exchange all_gather for the all-gather BASELINE names), emitted
-          pairs go to the owner of their smaller id, owners score, reverse edges go to the owner of
-          the larger id, every rank cuts its own top-K.
+          all-to-all by default, --exchange all_gather for the all-gather BASELINE names), every emitted
+          pair goes to the rank that scores it (the owner of one of its two queries, picked by a hash bit:
+          an even split for any data), scored edges go to the owner of their source query, every rank
+          cuts its own top-K.
 `--nq Q` switches to weak scaling (Q queries per GPU); `--nq-total T` picks another total size.
 configs[1] (1 M queries) is timed as a secondary figure of the N = 1 line, next to the two "next" rows
 of SURVEY 8f that feed / consume the path (answer-set construction N2, prediction loop N1).
@@ -93,7 +94,8 @@ def algorithmic_bytes_per_step(w):
     ib = max(1, (w["nq_total"] - 1).bit_length())
     g = w.get("group_bits", 0)                    # low bits of i the grouping sort skips (ops.row_group_bits)
     pair_passes = -(-(ib - g) // 8)               # pairs are grouped by i >> g only; rows are finished in LDS
-    edge_passes = -(-(ib + 11) // 8)
+    sel = w.get("topk", "select") == "select"     # top-K by rank-in-list: only the n reverse words are sorted, on j
+    edge_words = -(-ib // 8) * un if sel else -(-(ib + 11) // 8) * 2 * un   # key-passes of the top-K sort
     levels = 1 if w.get("part_bits", 8) <= 8 else 2
     out = {
         # CSR in (4 B/row id + 8 B offset); signature row, fused band keys and norm out
@@ -105,15 +107,22 @@ def algorithmic_bytes_per_step(w):
         "bucket_fill": 12 * rec + 8 * em,
         "bucket_emit": 12 * rec + 8 * em,             # one-pass form (cursor-reserved output ranges)
         # keys-only LSD passes: pair words, then directed edge keys
-        "sort_scatter_k": 16 * (pair_passes * em + edge_passes * 2 * un),
-        "sort_hist": 8 * (pair_passes * em + edge_passes * 2 * un),
+        "sort_scatter_k": 16 * (pair_passes * em + edge_words),
+        "sort_hist": 8 * (pair_passes * em + edge_words),
         # rows de-duplicated and ordered in LDS: emitted words in, distinct words out; then the gaps closed
         "row_unique": 8 * em + 8 * un,
         "row_unique_gather": 16 * un,
+        "region_unique": 8 * em + 8 * un,             # the same step, one workgroup per 2^g consecutive queries
+        "region_gather": 16 * un,
         # two signature rows + pair word in; score + two edge keys out
-        "score_pairs": (2 * sb * P + 8 + 4 + 16) * un,
+        "score_pairs": (2 * sb * P + 8 + 4 + (8 if sel else 16)) * un,
         "topk_count": 8 * 2 * un,
         "topk_fill": 8 * 2 * un + 12 * kept,
+        # select form: run starts of both lists (words in, nq + 1 starts out, twice); every edge reads its own
+        # record once (pair + score, reverse word) and writes its output row if it is kept -- the walk over its
+        # query's runs re-reads words its neighbours in the wave have just fetched (cache, not HBM)
+        "topk_bounds": 2 * (8 * un + 4 * nq),
+        "topk_select": (8 + 4 + 8) * un + 12 * kept + 16 * nq,
     }
     return out
 
@@ -250,7 +259,8 @@ def main():
         w = dict(nq=nq_local, nq_total=nq_total, nq_sorted=(rec_q // world if sharded else nq_local),
                  P=P, b=b, nnz=nnz, emitted=int(res.stats.get("emitted_pairs", 0)), unique=int(res.pairs.numel()),
                  kept=int(res.src.numel()), sig_bytes=2 if res.sig.dtype == torch.int16 else 4,
-                 group_bits=int(res.stats.get("group_bits", 0)), part_bits=int(res.stats.get("part_bits", 8)))
+                 group_bits=int(res.stats.get("group_bits", 0)), part_bits=int(res.stats.get("part_bits", 8)),
+                 topk=("sort" if sharded and world > 1 else res.stats.get("topk", "select")))
         ab = algorithmic_bytes_per_step(w)
         sb_tab = 2 if D <= 65536 else 4
         traffic, traffic_src, traffic_why = load_traffic(nq_total, P, b) if not sharded else ({}, None, "N > 1")

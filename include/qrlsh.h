@@ -197,6 +197,22 @@ int qrlsh_row_unique_count(const uint64_t *grouped, int64_t n, int32_t group_bit
                            void *stream);
 int qrlsh_row_unique_fill(const uint64_t *tmp, int64_t n, const void *workspace, uint64_t *out, void *stream);
 
+/* The same result from words grouped by i >> group_bits with group_bits up to 8 (REGIONS of 2^group_bits
+ * consecutive queries, a few thousand words each: at 2^24 ids and group_bits = 8 the grouping sort needs two
+ * radix passes, not three): one workgroup per region streams its words through an LDS hash set of the 32-bit
+ * values (i's low bits, j), counts the distinct ones per i, and places each by the number of smaller ones of
+ * its own i.  Only the DISTINCT pairs of a region are bounded, not its words: about 5 K in the main kernel,
+ * about 11 K in the big-image kernel that takes over the regions beyond that (very popular queries).  nids = number of query
+ * ids (regions = ceil(nids / 2^group_bits)); needs group_bits + id_bits <= 32, and nids < 2^id_bits when it is
+ * exactly 32.  count / fill / overflow as qrlsh_row_unique_*.  This is the default de-duplication of the
+ * pipeline; qrlsh_row_unique_* remains for id widths that leave no room for group bits. */
+size_t qrlsh_region_unique_workspace_bytes(int64_t nids, int32_t group_bits);
+int qrlsh_region_unique_count(const uint64_t *grouped, int64_t n, int32_t group_bits, int32_t id_bits, int64_t nids,
+                              uint64_t *tmp, void *workspace, size_t workspace_bytes, uint64_t *total_overflow_out,
+                              void *stream);
+int qrlsh_region_unique_fill(const uint64_t *tmp, int64_t n, int32_t group_bits, int64_t nids, const void *workspace,
+                             uint64_t *out, void *stream);
+
 /* ---- a5: pair scoring ------------------------------------------------------------
  * Replaces the cosine of recommender.py:203-204 for one candidate pair:
  *     np.around(cosine_similarity([sig_i, sig_j])[0][1], 3)
@@ -236,6 +252,26 @@ int qrlsh_topk_fill(const uint64_t *sorted_edges, const uint32_t *sorted_dst, in
 int qrlsh_topk_fill_based(const uint64_t *sorted_edges, const uint32_t *sorted_dst, int64_t n_edges, int32_t K,
                           int32_t id_bits, int64_t src_base, const void *workspace, int32_t *src_out,
                           int32_t *dst_out, int32_t *milli_out, void *stream);
+
+/* Select form of the same cut, without sorting the directed edges: the forward edges of a query are its run of
+ * the (sorted) scored pair list; only the n reverse words qrlsh_score_pairs_rev writes (rev_out[t] =
+ * j << (id_bits + 11) | inv << id_bits | i, or key + payload j << 11 | inv, i for ids beyond 26 bits) are
+ * sorted, stably, on j's bits alone -- ceil(id_bits / 8) passes over n words instead of ceil((id_bits + 11) / 8)
+ * over 2n.  Every directed edge then counts the edges of its query's two runs that order before it (value
+ * descending, neighbour id ascending; at most K of them are looked for) and, if fewer than K do, lands at that
+ * rank of its query's output row.  count: *total_out = number of edges kept; fill writes the same (src, dst,
+ * milli) COO qrlsh_topk_fill does.  nq = number of query ids; n < 2^31 pairs.
+ */
+int qrlsh_score_pairs_rev(const void *sig, int32_t sig_dtype, const int64_t *norm2, int32_t P,
+                          const uint64_t *pairs, int64_t n, int32_t *milli_out, uint64_t *rev_out, int32_t id_bits,
+                          uint32_t *rev_dst_out, void *stream);
+size_t qrlsh_topk_select_workspace_bytes(int64_t nq);
+int qrlsh_topk_select_count(const uint64_t *pairs, int64_t n, const uint64_t *rev_sorted, const uint32_t *rev_dst,
+                            int64_t nq, int32_t K, int32_t id_bits, void *workspace, size_t workspace_bytes,
+                            uint64_t *total_out, void *stream);
+int qrlsh_topk_select_fill(const uint64_t *pairs, const int32_t *milli, int64_t n, const uint64_t *rev_sorted,
+                           const uint32_t *rev_dst, int64_t nq, int32_t K, int32_t id_bits, const void *workspace,
+                           int32_t *src_out, int32_t *dst_out, int32_t *milli_out, void *stream);
 
 /* ---- multi-GPU glue (one process per GPU; qrlsh/dist.py) ----------------------------------------------
  * remap_pairs: an owner scores pairs (i local, j anywhere) against a row table [its nql local rows | the
@@ -314,13 +350,31 @@ int qrlsh_answer_sets_compact(const int32_t *slots, const int64_t *offsets, int6
  * neighbours in CSR form (q_off[nq+1], q_idx, q_val = rounded cosine, i.e. milli / 1000.0) as
  * qrlsh_topk_* produce them; user neighbours padded [nu][ku] (u_idx = -1 past the end).
  * out[nu][nq] = the utility matrix with every zero cell replaced by round(blend) (0 when neither
- * side predicts).  float64 arithmetic in the reference's order (numpy pairwise sums, no FMA,
- * round half to even).  ku <= 64 and at most 64 neighbours per query are used.
+ * side predicts).  float64 arithmetic, no FMA, round half to even.  sum_order picks the order of the two
+ * np.sum calls inside weighted_average: QRLSH_SUM_PAIRWISE = numpy's pairwise sum (the reference run as
+ * plain Python; the order the committed fixtures pin), QRLSH_SUM_SEQUENTIAL = one accumulator in index
+ * order (what numba's nopython np.sum does where numba is installed; unpinned here).
+ * Limits: ku <= 64 (QRLSH_EINVAL otherwise); a query with more than 64 neighbours sets *too_long_out
+ * (device uint32, required) to 1 and its column is not to be trusted -- the caller reads the flag back.
  */
+#define QRLSH_SUM_PAIRWISE 0
+#define QRLSH_SUM_SEQUENTIAL 1
 int qrlsh_predict(const int32_t *ratings, int64_t nu, int64_t nq, const int64_t *q_off,
                   const int32_t *q_idx, const double *q_val, const int32_t *u_idx, const double *u_val,
                   int32_t ku, double query_weight, double user_weight, double default_mean,
-                  int32_t *out, void *stream);
+                  int32_t sum_order, int32_t *out, uint32_t *too_long_out, void *stream);
+
+/* ---- N4: user similarity, the part after the clustering ----------------------------------------
+ * Recommender.compute_userSimilarities, recommender.py:263-288: inside a cluster every user's row is centred on
+ * the mean of its non-zero ratings IN AN INTEGER ARRAY (the centred values are truncated toward zero), then
+ * cosine of every pair of rows.  out[u][c] = ratings[u][c] == 0 ? 0 : (int)((double)ratings[u][c] - mean_u),
+ * mean_u = (double)sum / (double)count over the non-zero ratings; row stride nq_stride >= nq (padding = 0).
+ * The pairs of a cluster are qrlsh_bucket_pairs_emit on the labels (one band), their cosine qrlsh_score_pairs
+ * on these rows, the per-user cut qrlsh_topk_select_* (qrlsh/users.py).  The clustering itself (:226-261) is
+ * the reference's scikit-learn call and stays on the host.
+ */
+int qrlsh_center_rows(const int32_t *ratings, int64_t nu, int64_t nq, int64_t nq_stride, int32_t *out,
+                      void *stream);
 
 /* ---- synthetic answer sets (bench / test input) ---------------
  * Bit-identical twin of oracle/qr_oracle.c:qro_synth_*: a pure function of (seed, q).

@@ -326,20 +326,14 @@ def u64_to_pairs(p):
 QUERY_WEIGHT, USER_WEIGHT, DEFAULT_MEAN = 0.6, 0.4, 60   # recommender.py:32-34
 
 
-def user_similarities(ratings):
-    """recommender.py:216-290 restated: StandardScaler -> PCA(min(r, c, 200)) -> BIRCH with
-    round(nu ** (1/1.3)) clusters, singleton clusters pooled; per cluster the rows are centred on
-    their non-zero mean IN PLACE IN THE INTEGER ARRAY (the reference's np.array(self.ratings[...])
-    keeps the integer dtype, so the centred values are truncated toward zero), cosine, round to 3,
-    zero diagonal and negatives; per user the top K = round(log_1.5 nu) of its cluster row.
-    -> {u: {'indexes': int64[], 'values': float64[]}}"""
+def user_cluster_labels(ratings):
+    """recommender.py:226-261: StandardScaler -> PCA(min(r, c, 200)) -> BIRCH with round(nu ** (1/1.3))
+    clusters; clusters of one user are pooled under the label n_clusters.  -> int labels [nu]"""
     from sklearn.cluster import Birch
     from sklearn.decomposition import PCA
-    from sklearn.metrics.pairwise import cosine_similarity
     from sklearn.preprocessing import StandardScaler
     ratings = np.asarray(ratings)
     nu = ratings.shape[0]
-    K = round(math.log(nu, 1.5))
     n_clusters = round(nu ** (1 / 1.3))
     x = StandardScaler().fit_transform(ratings)
     x = PCA(n_components=min(x.shape[0], x.shape[1], 200)).fit(x).transform(x)
@@ -348,6 +342,20 @@ def user_similarities(ratings):
     for c in range(counts.size):
         if counts[c] == 1:
             labels[labels == c] = n_clusters
+    return labels
+
+
+def user_similarities_from_labels(ratings, labels):
+    """recommender.py:263-288 given the cluster labels: per cluster the rows are centred on
+    their non-zero mean IN PLACE IN THE INTEGER ARRAY (the reference's np.array(self.ratings[...])
+    keeps the integer dtype, so the centred values are truncated toward zero), cosine, round to 3,
+    zero diagonal and negatives; per user the top K = round(log_1.5 nu) of its cluster row.
+    -> {u: {'indexes': int64[], 'values': float64[]}}"""
+    from sklearn.metrics.pairwise import cosine_similarity
+    ratings = np.asarray(ratings)
+    labels = np.asarray(labels)
+    nu = ratings.shape[0]
+    K = round(math.log(nu, 1.5))
     out = {}
     for c in np.unique(labels):
         members = np.where(labels == c)[0]
@@ -362,6 +370,12 @@ def user_similarities(ratings):
             order = np.argsort(sim[local])[::-1][:K]
             out[int(u)] = {"indexes": members[order].astype(np.int64), "values": sim[local][order]}
     return out
+
+
+def user_similarities(ratings):
+    """recommender.py:216-290 restated: cluster labels (sklearn, as the reference), then the centred cosine
+    inside every cluster and the per-user cut."""
+    return user_similarities_from_labels(ratings, user_cluster_labels(ratings))
 
 
 def np_sum_order(a):

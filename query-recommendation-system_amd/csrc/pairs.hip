@@ -700,6 +700,264 @@ QRLSH_EXPORT int qrlsh_row_unique_fill(const uint64_t *tmp, int64_t n, const voi
   return QRLSH_OK;
 }
 
+// ---- a3 tail, region form: sorted unique pairs from pairs grouped by i >> g, g up to 8 ---------------
+// row_unique above finishes rows that a workgroup discovers inside a fixed chunk of the input; its cost is the
+// bookkeeping of that discovery (row starts / ends / overhang, per-position arrays) and, at 2^24 ids, the three
+// grouping passes that make single-i rows.  Here a REGION is the set of words whose i share their bits above
+// g (2^g consecutive queries, a few thousand words): the grouping sort orders the words by i >> g only -- at
+// 2^24 ids and g = 8 that is TWO radix passes -- and one workgroup finishes one region:
+//   1. the words are streamed from global memory (never staged) into an open-addressing hash set in LDS keyed
+//      by the 32-bit value (i's low g bits, j); a first insertion also counts the value for its i (256 counters);
+//   2. the counters are scanned -> where each i's distinct values start in the output;
+//   3. the occupied slots are dealt to their i's segment, then every value finds its place by counting the
+//      smaller ones of its own i (a handful).
+// Only the number of DISTINCT pairs of a region is bounded by LDS, not its word count, so an i with thousands
+// of repeated emissions is no special case: about 5 K per region in the main kernel (two workgroups per CU),
+// about 11 K in the big-image kernel that takes over the few regions beyond that; a region beyond THAT raises
+// the overflow word and the caller takes the general path.  Region boundaries come from a binary search per region (the words are
+// ordered by region), outputs are packed by the same count -> scan -> gather as above.
+constexpr int RG_THREADS = 1024;
+constexpr int RG_SEG = 6144;     // distinct pairs a region may hold
+constexpr int RG_ROWS = 256;     // 2^g <= 256
+
+__global__ __launch_bounds__(256) void region_bounds_kernel(const uint64_t *__restrict__ w, int64_t n, int shift,
+                                                            int64_t nregions, uint64_t *__restrict__ starts) {
+  const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f > nregions) return;
+  int64_t a = 0, b = n;  // first position whose region is >= f
+  while (a < b) {
+    const int64_t mid = (a + b) >> 1;
+    if ((int64_t)(w[mid] >> shift) >= f) b = mid;
+    else a = mid + 1;
+  }
+  starts[f] = (uint64_t)a;
+}
+
+// One region, finished by the calling workgroup (RG_THREADS threads).  TAB_LOG2 / SEG size the hash set and the
+// segment array.  Returns false (uniform) when the region holds more than SEG distinct pairs.
+template <int TAB_LOG2, int SEG>
+__device__ static inline bool region_finish(const uint64_t *__restrict__ in, int64_t s0, int64_t s1, int64_t region,
+                                            uint64_t *__restrict__ tmp, uint64_t *__restrict__ counts, int gbits,
+                                            int jbits) {
+  constexpr int TAB = 1 << TAB_LOG2;
+  __shared__ uint32_t tab[TAB];
+  __shared__ uint32_t seg[SEG];
+  __shared__ uint32_t rowcnt[RG_ROWS], rowstart[RG_ROWS + 1], rowfill[RG_ROWS];
+  __shared__ uint32_t wsum[RG_ROWS / WAVE];
+  __shared__ uint32_t full, ndist;
+  const int t = threadIdx.x, lane = t & (WAVE - 1), wv = t >> 6;
+#pragma unroll
+  for (int k = 0; k < TAB / RG_THREADS; ++k) tab[t + k * RG_THREADS] = RD_EMPTY;
+  if (t < RG_ROWS) {
+    rowcnt[t] = 0;
+    rowfill[t] = 0;
+  }
+  if (t == 0) {
+    full = 0;
+    ndist = 0;
+  }
+  __syncthreads();
+  const uint32_t gmask = (1u << gbits) - 1u, jmask = (1u << jbits) - 1u;  // jbits <= 31 here (checked by the host)
+  // 1. stream the words into the hash set, four independent loads in flight per thread
+  for (int64_t p0 = s0 + t; p0 < s1; p0 += 4 * RG_THREADS) {
+    uint64_t x[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t p = p0 + (int64_t)k * RG_THREADS;
+      x[k] = p < s1 ? in[p] : ~0ull;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (p0 + (int64_t)k * RG_THREADS >= s1) continue;
+      const uint32_t row = (uint32_t)(x[k] >> 32) & gmask;
+      const uint32_t v = row << jbits | ((uint32_t)x[k] & jmask);
+      uint32_t slot = (v * 0x9E3779B1u) >> (32 - TAB_LOG2);
+      // the set never takes more than SEG values (SEG < TAB: a free slot always turns up); once it would, the
+      // region is given up and the remaining words are skipped
+      while (!*(volatile uint32_t *)&full) {
+        const uint32_t old = atomicCAS(&tab[slot], RD_EMPTY, v);
+        if (old == RD_EMPTY) {
+          atomicAdd(&rowcnt[row], 1u);
+          if (atomicAdd(&ndist, 1u) >= (uint32_t)SEG - RG_THREADS) full = 1;  // (up to RG_THREADS inserts are in flight)
+          break;
+        }
+        if (old == v) break;
+        slot = (slot + 1) & (TAB - 1);
+      }
+    }
+    if (*(volatile uint32_t *)&full) break;
+  }
+  __syncthreads();
+  // 2. where each i's distinct values start: exclusive scan of the 256 counters
+  uint32_t c = 0, inc = 0;
+  if (t < RG_ROWS) {
+    c = rowcnt[t];
+    inc = c;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+      const uint32_t o = __shfl_up(inc, d, WAVE);
+      if (lane >= d) inc += o;
+    }
+    if (lane == WAVE - 1) wsum[wv] = inc;
+  }
+  __syncthreads();
+  if (t < RG_ROWS) {
+    uint32_t base = 0;
+#pragma unroll
+    for (int k = 0; k < RG_ROWS / WAVE; ++k)
+      if (k < wv) base += wsum[k];
+    rowstart[t] = base + inc - c;
+    if (t == RG_ROWS - 1) rowstart[RG_ROWS] = base + inc;
+  }
+  __syncthreads();
+  const uint32_t u = rowstart[RG_ROWS];
+  const bool fits = !full;   // full: SEG - RG_THREADS distinct values were reached (u <= SEG either way)
+  __syncthreads();  // every thread has read `full` / `u` before the arrays are touched again (or re-initialised)
+  if (!fits) return false;
+  // 3. deal the occupied slots to their i's segment ...
+#pragma unroll
+  for (int k = 0; k < TAB / RG_THREADS; ++k) {
+    const uint32_t v = tab[t + k * RG_THREADS];
+    if (v != RD_EMPTY) {
+      const uint32_t row = v >> jbits;
+      seg[rowstart[row] + atomicAdd(&rowfill[row], 1u)] = v;
+    }
+  }
+  __syncthreads();
+  // ... and place every value by the number of smaller ones of its own i
+  const uint64_t ihigh = (uint64_t)region << gbits;
+  uint64_t *dst = tmp + s0;
+  for (uint32_t k = t; k < u; k += RG_THREADS) {
+    const uint32_t v = seg[k], row = v >> jbits;
+    const uint32_t rs = rowstart[row], re = rowstart[row + 1];
+    uint32_t r = 0;
+    for (uint32_t q = rs; q < re; ++q) r += seg[q] < v;
+    dst[rs + r] = (ihigh | row) << 32 | (v & jmask);
+  }
+  if (t == 0) counts[region] = u;
+  __syncthreads();  // the big kernel re-uses the arrays for its next region
+  return true;
+}
+
+__global__ __launch_bounds__(RG_THREADS, 8) void region_unique_kernel(const uint64_t *__restrict__ in,
+                                                                      const uint64_t *__restrict__ starts,
+                                                                      uint64_t *__restrict__ tmp,
+                                                                      uint64_t *__restrict__ counts,
+                                                                      uint64_t *__restrict__ biglist,
+                                                                      unsigned long long *__restrict__ nbig, int gbits,
+                                                                      int jbits) {
+  const int64_t region = blockIdx.x;
+  const int64_t s0 = (int64_t)starts[region], s1 = (int64_t)starts[region + 1];
+  if (s0 == s1) {  // uniform
+    if (threadIdx.x == 0) counts[region] = 0;
+    return;
+  }
+  if (!region_finish<13, RG_SEG>(in, s0, s1, region, tmp, counts, gbits, jbits) && threadIdx.x == 0) {
+    // more distinct pairs than this image holds (a few very popular queries): left to the big-image kernel
+    counts[region] = 0;
+    biglist[__hip_atomic_fetch_add(nbig, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = (uint64_t)region;
+  }
+}
+
+// Regions the kernel above could not hold: the same finish with a 16384-slot set and a 12288-value segment
+// (one workgroup per CU), from a fixed grid that walks the device-side list -- nothing is read back to size
+// the launch.  A region beyond THAT raises the overflow word (general path).
+constexpr int RG_BIG_SEG = 12288;
+constexpr int RG_BIG_GRID = 256;
+__global__ __launch_bounds__(RG_THREADS, 4) void region_unique_big_kernel(const uint64_t *__restrict__ in,
+                                                                          const uint64_t *__restrict__ starts,
+                                                                          uint64_t *__restrict__ tmp,
+                                                                          uint64_t *__restrict__ counts,
+                                                                          const uint64_t *__restrict__ biglist,
+                                                                          const unsigned long long *__restrict__ nbig,
+                                                                          uint64_t *__restrict__ overflow, int gbits,
+                                                                          int jbits) {
+  const unsigned long long nb = *nbig;
+  for (unsigned long long e = blockIdx.x; e < nb; e += gridDim.x) {
+    const int64_t region = (int64_t)biglist[e];
+    const int64_t s0 = (int64_t)starts[region], s1 = (int64_t)starts[region + 1];
+    if (!region_finish<14, RG_BIG_SEG>(in, s0, s1, region, tmp, counts, gbits, jbits) && threadIdx.x == 0)
+      atomicOr((unsigned long long *)overflow, 1ull);
+  }
+}
+
+// close the gaps: workgroup r copies its counts[r] words from tmp[starts[r] ..) to out[offs[r] ..)
+__global__ __launch_bounds__(256) void region_gather_kernel(const uint64_t *__restrict__ tmp,
+                                                            const uint64_t *__restrict__ offs,
+                                                            const uint64_t *__restrict__ starts,
+                                                            uint64_t *__restrict__ out) {
+  const size_t r = blockIdx.x;
+  const uint64_t o0 = offs[r], cnt = offs[r + 1] - o0;
+  const uint64_t *src = tmp + starts[r];
+  for (uint32_t k = threadIdx.x; k < cnt; k += 256) out[o0 + k] = src[k];
+}
+
+// workspace: starts[nregions + 1] | counts[nregions + 1] | biglist[nregions] | nbig | chunk totals of the scan
+static int64_t region_count(int64_t nids, int gbits) { return (nids + (1ll << gbits) - 1) >> gbits; }
+
+QRLSH_EXPORT size_t qrlsh_region_unique_workspace_bytes(int64_t nids, int32_t group_bits) {
+  if (nids <= 0 || group_bits < 0 || group_bits > 8) return 64;
+  const int64_t nr = region_count(nids, group_bits);
+  return (size_t)(3 * (nr + 1) + ceil_div64(nr + 1, SCANL_CHUNK) + 2) * sizeof(uint64_t);
+}
+
+QRLSH_EXPORT int qrlsh_region_unique_count(const uint64_t *grouped, int64_t n, int32_t group_bits, int32_t id_bits,
+                                           int64_t nids, uint64_t *tmp, void *workspace, size_t workspace_bytes,
+                                           uint64_t *total_overflow_out, void *stream) {
+  QR_CHECK_ARG(n >= 0 && total_overflow_out && nids > 0 && nids <= (1ll << 32), "qrlsh_region_unique_count: bad arguments");
+  // the 32-bit value (i's low bits, j) must never be the empty-slot marker 0xFFFFFFFF: either it has a spare
+  // bit, or the largest j (nids - 1) is not all ones
+  QR_CHECK_ARG(group_bits >= 0 && group_bits <= 8 && id_bits >= 1 && id_bits <= 32 && nids <= (1ll << id_bits) &&
+                   (group_bits + id_bits < 32 || (group_bits + id_bits == 32 && nids < (1ll << id_bits))),
+               "qrlsh_region_unique_count: group_bits=%d / id_bits=%d (need group_bits <= 8, group_bits + id_bits <= 32)",
+               group_bits, id_bits);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(total_overflow_out, 0, 2 * sizeof(uint64_t), st) != hipSuccess) {
+    qrlsh_set_error("qrlsh_region_unique_count: hipMemsetAsync failed");
+    return QRLSH_EHIP;
+  }
+  if (n == 0) return QRLSH_OK;
+  QR_CHECK_ARG(grouped && tmp && workspace, "qrlsh_region_unique_count: null pointer");
+  if (workspace_bytes < qrlsh_region_unique_workspace_bytes(nids, group_bits)) {
+    qrlsh_set_error("qrlsh_region_unique_count: workspace %zu < %zu bytes", workspace_bytes,
+                    qrlsh_region_unique_workspace_bytes(nids, group_bits));
+    return QRLSH_EWORKSPACE;
+  }
+  const int64_t nr = region_count(nids, group_bits);
+  QR_CHECK_ARG(nr <= 2147483647ll, "qrlsh_region_unique_count: too many regions");
+  uint64_t *starts = static_cast<uint64_t *>(workspace), *counts = starts + (nr + 1), *biglist = counts + (nr + 1);
+  uint64_t *nbig = biglist + nr, *sums = nbig + 1;
+  if (hipMemsetAsync(counts + nr, 0, sizeof(uint64_t), st) != hipSuccess ||
+      hipMemsetAsync(nbig, 0, sizeof(uint64_t), st) != hipSuccess) {
+    qrlsh_set_error("qrlsh_region_unique_count: hipMemsetAsync failed");
+    return QRLSH_EHIP;
+  }
+  QR_LAUNCH("region_bounds", region_bounds_kernel, dim3((unsigned)ceil_div64(nr + 1, 256)), dim3(256), 0, st, grouped, n,
+            32 + group_bits, nr, starts);
+  QR_LAUNCH("region_unique", region_unique_kernel, dim3((unsigned)nr), dim3(RG_THREADS), 0, st, grouped,
+            (const uint64_t *)starts, tmp, counts, biglist, reinterpret_cast<unsigned long long *>(nbig), group_bits,
+            id_bits);
+  QR_LAUNCH("region_unique_big", region_unique_big_kernel, dim3((unsigned)(nr < RG_BIG_GRID ? nr : RG_BIG_GRID)),
+            dim3(RG_THREADS), 0, st, grouped, (const uint64_t *)starts, tmp, counts, (const uint64_t *)biglist,
+            (const unsigned long long *)nbig, total_overflow_out + 1, group_bits, id_bits);
+  qr_scan_u64(counts, nr + 1, total_overflow_out, sums, st);
+  QR_LAUNCH_CHECK("qrlsh_region_unique_count");
+  return QRLSH_OK;
+}
+
+QRLSH_EXPORT int qrlsh_region_unique_fill(const uint64_t *tmp, int64_t n, int32_t group_bits, int64_t nids,
+                                          const void *workspace, uint64_t *out, void *stream) {
+  QR_CHECK_ARG(n >= 0 && nids > 0 && group_bits >= 0 && group_bits <= 8, "qrlsh_region_unique_fill: bad arguments");
+  if (n == 0) return QRLSH_OK;
+  QR_CHECK_ARG(tmp && workspace && out, "qrlsh_region_unique_fill: null pointer");
+  const int64_t nr = region_count(nids, group_bits);
+  const uint64_t *starts = static_cast<const uint64_t *>(workspace), *offs = starts + (nr + 1);
+  QR_LAUNCH("region_gather", region_gather_kernel, dim3((unsigned)nr), dim3(256), 0, static_cast<hipStream_t>(stream), tmp,
+            offs, starts, out);
+  QR_LAUNCH_CHECK("qrlsh_region_unique_fill");
+  return QRLSH_OK;
+}
+
 QRLSH_EXPORT int qrlsh_topk_count(const uint64_t *sorted_edges, int64_t n_edges, int32_t K, int32_t id_bits,
                                   void *workspace, size_t workspace_bytes, uint64_t *total_out, void *stream) {
   // id_bits == 0 selects the wide-id edge format (src << 11 | inv, dst as payload)
@@ -729,5 +987,296 @@ QRLSH_EXPORT int qrlsh_topk_fill_based(const uint64_t *sorted_edges, const uint3
                      id_bits, sorted_dst, static_cast<const uint64_t *>(workspace), nullptr, src_out, dst_out, milli_out,
                      (int32_t)src_base);
   QR_LAUNCH_CHECK("qrlsh_topk_fill");
+  return QRLSH_OK;
+}
+
+// ---- a5 tail, select form: per-query top-K without sorting the directed edges ---------------------------
+// The sort form above orders all 2n directed edge keys on (src, 1000 - milli): ceil((id_bits + 11) / 8) radix
+// passes over 2n words.  But the forward edges (src = i) ARE the scored pair list, already grouped by src and
+// ordered by dst; only the n reverse edges (src = j) have to be brought together, and for that a stable sort on
+// j's bits alone is enough (ceil(id_bits / 8) passes over n words -- under a third of the key-passes).  A query's
+// neighbours are then two runs, [fstart[q], fstart[q+1]) of the pairs and [rstart[q], rstart[q+1]) of the sorted
+// reverse words, and every directed edge finds its rank in its query's list by counting the edges of those two
+// runs that order before it (value descending, then neighbour id ascending) -- stopping as soon as K of them
+// have been seen, so a very popular query costs ~K n log(n / K) compares, not n^2.  Edge of rank r < K goes to
+// out[off[q] + r], off = exclusive scan of min(K, list length): the output is the same (src, value desc, dst
+// asc) COO the sort form writes, bit for bit.
+// Reverse words: packed  j << (id_bits + 11) | inv << id_bits | i  (rdst == NULL), or key + payload
+// (j << 11 | inv, i) for ids that do not fit.
+__device__ static inline uint32_t rev_src(uint64_t w, int id_bits, bool wide) {
+  return (uint32_t)(wide ? w >> 11 : w >> (id_bits + 11));
+}
+
+// start[q] = first position of `a` whose src is >= q (q = 0 .. nq); a is ordered by src.  FWD: a = pairs, src = i.
+template <bool FWD>
+__global__ __launch_bounds__(256) void edge_bounds_kernel(const uint64_t *__restrict__ a, int64_t n, int64_t nq,
+                                                          int id_bits, int wide, uint32_t *__restrict__ start) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t > n) return;
+  const int64_t s = t < n ? (int64_t)(FWD ? (uint32_t)(a[t] >> 32) : rev_src(a[t], id_bits, wide != 0)) : nq;
+  const int64_t p = t > 0 ? (int64_t)(FWD ? (uint32_t)(a[t - 1] >> 32) : rev_src(a[t - 1], id_bits, wide != 0)) : -1;
+  for (int64_t q = p + 1; q <= s && q <= nq; ++q) start[q] = (uint32_t)t;
+}
+
+constexpr int SEL_LONG = 96;    // lists longer than this go to the wave-per-query kernel
+constexpr int SEL_MAXK = 256;   // largest K of the select form (the sort form has no limit)
+constexpr int SEL_LONG_GRID = 1024;
+
+__global__ __launch_bounds__(256) void topk_len_kernel(const uint32_t *__restrict__ fstart,
+                                                       const uint32_t *__restrict__ rstart, int64_t nq, int K,
+                                                       uint64_t *__restrict__ cnt, uint32_t *__restrict__ longlist,
+                                                       unsigned long long *__restrict__ nlong) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q > nq) return;
+  uint64_t c = 0;
+  if (q < nq) {
+    c = (uint64_t)(fstart[q + 1] - fstart[q]) + (rstart[q + 1] - rstart[q]);
+    if (c > (uint64_t)SEL_LONG)
+      longlist[__hip_atomic_fetch_add(nlong, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = (uint32_t)q;
+    if (c > (uint64_t)K) c = (uint64_t)K;
+  }
+  cnt[q] = c;  // one word past the end: the scan leaves the total there
+}
+
+// (inv << 32 | dst) of element x of a query's list: x < nr -> reverse run, else forward run
+__device__ static inline uint64_t sel_key(uint32_t x, uint32_t rs, uint32_t nr, uint32_t fs,
+                                          const uint64_t *__restrict__ pairs, const int32_t *__restrict__ milli,
+                                          const uint64_t *__restrict__ rev, const uint32_t *__restrict__ rdst,
+                                          int id_bits, uint64_t idm) {
+  if (x < nr) {
+    const uint64_t w = rev[rs + x];
+    return rdst ? (w & 0x7FFull) << 32 | rdst[rs + x] : ((w >> id_bits) & 0x7FFull) << 32 | (w & idm);
+  }
+  const uint32_t y = fs + (x - nr);
+  return (uint64_t)(uint32_t)(1000 - milli[y]) << 32 | (uint32_t)pairs[y];
+}
+
+__global__ __launch_bounds__(256) void topk_select_kernel(const uint64_t *__restrict__ pairs,
+                                                          const int32_t *__restrict__ milli, int64_t n,
+                                                          const uint64_t *__restrict__ rev,
+                                                          const uint32_t *__restrict__ rdst,
+                                                          const uint32_t *__restrict__ fstart,
+                                                          const uint32_t *__restrict__ rstart,
+                                                          const uint64_t *__restrict__ off, int K, int id_bits,
+                                                          int32_t *__restrict__ src_out, int32_t *__restrict__ dst_out,
+                                                          int32_t *__restrict__ milli_out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 2 * n) return;
+  const bool wide = rdst != nullptr;
+  const uint64_t idm = id_bits >= 32 ? 0xFFFFFFFFull : (1ull << id_bits) - 1ull;
+  uint32_t src, dst, inv;
+  if (e < n) {  // forward edge of pair e
+    const uint64_t pr = pairs[e];
+    src = (uint32_t)(pr >> 32);
+    dst = (uint32_t)pr;
+    inv = (uint32_t)(1000 - milli[e]);
+  } else {  // reverse edge
+    const uint64_t w = rev[e - n];
+    src = rev_src(w, id_bits, wide);
+    if (wide) {
+      inv = (uint32_t)(w & 0x7FFull);
+      dst = rdst[e - n];
+    } else {
+      inv = (uint32_t)((w >> id_bits) & 0x7FFull);
+      dst = (uint32_t)(w & idm);
+    }
+  }
+  const uint64_t mine = (uint64_t)inv << 32 | dst;
+  const uint32_t fs = fstart[src], nf = fstart[src + 1] - fs, rs = rstart[src], nr = rstart[src + 1] - rs;
+  const uint32_t len = nf + nr;
+  if (len > (uint32_t)SEL_LONG) return;  // a popular query: topk_select_long_kernel
+  uint32_t rank = 0;
+  for (uint32_t x0 = 0; x0 < len && rank < (uint32_t)K; x0 += 4) {  // four independent loads in flight
+    uint64_t k[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      k[c] = x0 + c < len ? sel_key(x0 + c, rs, nr, fs, pairs, milli, rev, rdst, id_bits, idm) : ~0ull;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) rank += k[c] < mine;
+  }
+  if (rank < (uint32_t)K) {
+    const uint64_t o = off[src] + rank;
+    src_out[o] = (int32_t)src;
+    dst_out[o] = (int32_t)dst;
+    milli_out[o] = 1000 - (int32_t)inv;
+  }
+}
+
+// Popular queries (lists beyond SEL_LONG): one wave per query, O(list length).  A histogram of the 2001
+// possible values (inv = 1000 - milli) locates the value v* at which the K-th neighbour sits; the neighbours
+// with inv < v* are all kept, and of those with inv == v* the first K - (number below) in list order -- the
+// list order (reverse run, then forward run) IS ascending neighbour id, the tie-break.  The <= K survivors then
+// rank themselves among each other.
+__global__ __launch_bounds__(256) void topk_select_long_kernel(const uint64_t *__restrict__ pairs,
+                                                               const int32_t *__restrict__ milli,
+                                                               const uint64_t *__restrict__ rev,
+                                                               const uint32_t *__restrict__ rdst,
+                                                               const uint32_t *__restrict__ fstart,
+                                                               const uint32_t *__restrict__ rstart,
+                                                               const uint64_t *__restrict__ off,
+                                                               const uint32_t *__restrict__ longlist,
+                                                               const unsigned long long *__restrict__ nlong, int K,
+                                                               int id_bits, int32_t *__restrict__ src_out,
+                                                               int32_t *__restrict__ dst_out,
+                                                               int32_t *__restrict__ milli_out) {
+  constexpr int NV = 2048;  // inv in [0, 2000]
+  __shared__ uint32_t hist_all[4][NV];
+  __shared__ uint64_t keep_all[4][SEL_MAXK];
+  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
+  uint32_t *hist = hist_all[wv];
+  uint64_t *keep = keep_all[wv];
+  const uint64_t idm = id_bits >= 32 ? 0xFFFFFFFFull : (1ull << id_bits) - 1ull;
+  const unsigned long long nl = *nlong;
+  const unsigned long long nwaves = (unsigned long long)gridDim.x * 4;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  for (unsigned long long e = (unsigned long long)blockIdx.x * 4 + wv; e < nl; e += nwaves) {
+    const uint32_t q = longlist[e];
+    const uint32_t fs = fstart[q], nf = fstart[q + 1] - fs, rs = rstart[q], nr = rstart[q + 1] - rs;
+    const uint32_t len = nf + nr;
+    for (int v = lane; v < NV; v += WAVE) hist[v] = 0;
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t x = lane; x < len; x += WAVE)
+      atomicAdd(&hist[(uint32_t)(sel_key(x, rs, nr, fs, pairs, milli, rev, rdst, id_bits, idm) >> 32)], 1u);
+    __builtin_amdgcn_wave_barrier();
+    // v* = smallest v with count(inv <= v) >= K; below = count(inv < v*).  Lane l owns values [32 l, 32 l + 32).
+    uint32_t mysum = 0;
+    for (int v = 0; v < NV / WAVE; ++v) mysum += hist[lane * (NV / WAVE) + v];
+    uint32_t inc = mysum;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+      const uint32_t o = __shfl_up(inc, d, WAVE);
+      if (lane >= d) inc += o;
+    }
+    const uint64_t reach = __ballot(inc >= (uint32_t)K);  // len > SEL_LONG >= ... may still be < K: then keep all
+    uint32_t vstar = NV, below = 0;
+    if (reach) {
+      const int owner = __ffsll((long long)reach) - 1;
+      uint32_t run = __shfl(inc - mysum, owner, WAVE);   // count below the owner's first value
+      uint32_t vs = NV, bl = 0;
+      if (lane == owner) {
+        for (int v = 0; v < NV / WAVE; ++v) {
+          const uint32_t h = hist[lane * (NV / WAVE) + v];
+          if (run + h >= (uint32_t)K) {
+            vs = lane * (NV / WAVE) + v;
+            bl = run;
+            break;
+          }
+          run += h;
+        }
+      }
+      vstar = __shfl(vs, owner, WAVE);
+      below = __shfl(bl, owner, WAVE);
+    }
+    const uint32_t want_eq = reach ? (uint32_t)K - below : 0u;  // ties at v* kept, in list order
+    // second sweep, in list order: collect the survivors
+    uint32_t nkeep = 0, neq = 0;
+    for (uint32_t x0 = 0; x0 < len; x0 += WAVE) {
+      const uint32_t x = x0 + lane;
+      const uint64_t k = x < len ? sel_key(x, rs, nr, fs, pairs, milli, rev, rdst, id_bits, idm) : ~0ull;
+      const uint32_t inv = (uint32_t)(k >> 32);
+      const bool lt = x < len && inv < vstar;
+      const bool eq = x < len && inv == vstar;
+      const uint64_t meq = __ballot(eq);
+      const bool take_eq = eq && neq + (uint32_t)__popcll(meq & lt_mask) < want_eq;
+      const uint64_t mk = __ballot(lt || take_eq);
+      if (lt || take_eq) keep[nkeep + (uint32_t)__popcll(mk & lt_mask)] = k;
+      nkeep += (uint32_t)__popcll(mk);
+      neq += (uint32_t)__popcll(meq);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // nkeep == min(K, len); rank the survivors among themselves
+    const uint64_t o0 = off[q];
+    for (uint32_t a = lane; a < nkeep; a += WAVE) {
+      const uint64_t k = keep[a];
+      uint32_t r = 0;
+      for (uint32_t c = 0; c < nkeep; ++c) r += keep[c] < k;
+      src_out[o0 + r] = (int32_t)q;
+      dst_out[o0 + r] = (int32_t)(uint32_t)k;
+      milli_out[o0 + r] = 1000 - (int32_t)(uint32_t)(k >> 32);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// workspace: fstart u32[nq + 1] | rstart u32[nq + 1] | longlist u32[nq] | off u64[nq + 2] | nlong | chunk totals of the scan
+struct SelWs {
+  uint32_t *fstart, *rstart, *longlist;
+  uint64_t *off, *nlong, *sums;
+  size_t bytes;
+};
+static SelWs sel_ws(void *workspace, int64_t nq) {
+  SelWs w;
+  char *p = static_cast<char *>(workspace);
+  size_t o = 0;
+  w.fstart = reinterpret_cast<uint32_t *>(p + o);
+  o += ((size_t)(nq + 1) * 4 + 15) & ~(size_t)15;
+  w.rstart = reinterpret_cast<uint32_t *>(p + o);
+  o += ((size_t)(nq + 1) * 4 + 15) & ~(size_t)15;
+  w.longlist = reinterpret_cast<uint32_t *>(p + o);
+  o += ((size_t)(nq + 1) * 4 + 15) & ~(size_t)15;
+  w.off = reinterpret_cast<uint64_t *>(p + o);
+  o += (size_t)(nq + 2) * 8;
+  w.nlong = reinterpret_cast<uint64_t *>(p + o);
+  o += 16;
+  w.sums = reinterpret_cast<uint64_t *>(p + o);
+  o += (size_t)(ceil_div64(nq + 1, SCANL_CHUNK) + 2) * 8;
+  w.bytes = o;
+  return w;
+}
+
+QRLSH_EXPORT size_t qrlsh_topk_select_workspace_bytes(int64_t nq) {
+  if (nq <= 0) return 64;
+  return sel_ws(nullptr, nq).bytes;
+}
+
+QRLSH_EXPORT int qrlsh_topk_select_count(const uint64_t *pairs, int64_t n, const uint64_t *rev_sorted,
+                                         const uint32_t *rev_dst, int64_t nq, int32_t K, int32_t id_bits, void *workspace,
+                                         size_t workspace_bytes, uint64_t *total_out, void *stream) {
+  QR_CHECK_ARG(n >= 0 && n < (1ll << 31) && nq > 0 && nq <= (1ll << 32) && K > 0 && K <= SEL_MAXK && id_bits >= 1 &&
+                   id_bits <= 32,
+               "qrlsh_topk_select_count: bad arguments (n=%lld nq=%lld K=%d (<= %d) id_bits=%d)", (long long)n,
+               (long long)nq, K, SEL_MAXK, id_bits);
+  QR_CHECK_ARG(rev_dst || id_bits <= 26, "qrlsh_topk_select_count: packed reverse words need id_bits <= 26");
+  QR_CHECK_ARG(total_out && workspace && (n == 0 || (pairs && rev_sorted)), "qrlsh_topk_select_count: null pointer");
+  if (workspace_bytes < qrlsh_topk_select_workspace_bytes(nq)) {
+    qrlsh_set_error("qrlsh_topk_select_count: workspace %zu < %zu bytes", workspace_bytes,
+                    qrlsh_topk_select_workspace_bytes(nq));
+    return QRLSH_EWORKSPACE;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const SelWs w = sel_ws(workspace, nq);
+  if (hipMemsetAsync(w.nlong, 0, sizeof(uint64_t), st) != hipSuccess) {
+    qrlsh_set_error("qrlsh_topk_select_count: hipMemsetAsync failed");
+    return QRLSH_EHIP;
+  }
+  const dim3 g1((unsigned)ceil_div64(n + 1, 256)), blk(256);
+  QR_LAUNCH("topk_bounds", (edge_bounds_kernel<true>), g1, blk, 0, st, pairs, n, nq, id_bits, 0, w.fstart);
+  QR_LAUNCH("topk_bounds", (edge_bounds_kernel<false>), g1, blk, 0, st, rev_sorted, n, nq, id_bits, rev_dst ? 1 : 0,
+            w.rstart);
+  QR_LAUNCH("topk_len", topk_len_kernel, dim3((unsigned)ceil_div64(nq + 1, 256)), blk, 0, st, (const uint32_t *)w.fstart,
+            (const uint32_t *)w.rstart, nq, K, w.off, w.longlist, reinterpret_cast<unsigned long long *>(w.nlong));
+  qr_scan_u64(w.off, nq + 1, total_out, w.sums, st);
+  QR_LAUNCH_CHECK("qrlsh_topk_select_count");
+  return QRLSH_OK;
+}
+
+QRLSH_EXPORT int qrlsh_topk_select_fill(const uint64_t *pairs, const int32_t *milli, int64_t n,
+                                        const uint64_t *rev_sorted, const uint32_t *rev_dst, int64_t nq, int32_t K,
+                                        int32_t id_bits, const void *workspace, int32_t *src_out, int32_t *dst_out,
+                                        int32_t *milli_out, void *stream) {
+  QR_CHECK_ARG(n >= 0 && n < (1ll << 31) && nq > 0 && K > 0 && K <= SEL_MAXK && id_bits >= 1 && id_bits <= 32,
+               "qrlsh_topk_select_fill: bad arguments");
+  if (n == 0) return QRLSH_OK;
+  QR_CHECK_ARG(pairs && milli && rev_sorted && workspace && src_out && dst_out && milli_out,
+               "qrlsh_topk_select_fill: null pointer");
+  const SelWs w = sel_ws(const_cast<void *>(workspace), nq);
+  QR_LAUNCH("topk_select", topk_select_kernel, dim3((unsigned)ceil_div64(2 * n, 256)), dim3(256), 0,
+            static_cast<hipStream_t>(stream), pairs, milli, n, rev_sorted, rev_dst, (const uint32_t *)w.fstart,
+            (const uint32_t *)w.rstart, (const uint64_t *)w.off, K, id_bits, src_out, dst_out, milli_out);
+  QR_LAUNCH("topk_select_long", topk_select_long_kernel, dim3(SEL_LONG_GRID), dim3(256), 0,
+            static_cast<hipStream_t>(stream), pairs, milli, rev_sorted, rev_dst, (const uint32_t *)w.fstart,
+            (const uint32_t *)w.rstart, (const uint64_t *)w.off, (const uint32_t *)w.longlist,
+            (const unsigned long long *)w.nlong, K, id_bits, src_out, dst_out, milli_out);
+  QR_LAUNCH_CHECK("qrlsh_topk_select_fill");
   return QRLSH_OK;
 }

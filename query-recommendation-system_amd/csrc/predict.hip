@@ -5,43 +5,90 @@
 //     qp = weighted_average(ratings[i],    query_sims[j])      (content-based, :313-317)
 //     up = weighted_average(ratings[:, j], user_sims[i])       (collaborative,  :320)
 // blended by the rules of :324-331 and rounded with Python's round() (half to even).
-// One thread per cell; every cell is independent.  The arithmetic is kept bit-compatible with
-// the reference's float64 evaluation: this file is compiled with -ffp-contract=off, sums follow
-// numpy's pairwise order (what np.sum does in weighted_average), the blend is evaluated in
-// the reference's operand order, and rint() is round-half-to-even like round().
+// One thread per cell; every cell is independent.  float64 throughout, compiled with
+// -ffp-contract=off, the blend evaluated in the reference's operand order, rint() = round-half-to-even.
+//
+// Order of the two sums inside weighted_average (np.sum(ur * vals) and np.sum(vals[ur != 0])):
+//   QRLSH_SUM_PAIRWISE   numpy's pairwise_sum (8 running sums, combined as a tree, tail added one by one):
+//                        what np.sum does when weighted_average runs as plain Python.  The golden fixtures
+//                        (tests/golden/cfg1*_scores.npz) were captured that way -- numba is not installable
+//                        here, tools/make_golden.py replaces @jit by the identity -- so THIS order is the one
+//                        parity is pinned for.
+//   QRLSH_SUM_SEQUENTIAL one accumulator, index order: what numba's nopython np.sum compiles to, i.e. what
+//                        the reference computes where numba is installed.  Unpinned (no fixture can be made
+//                        here); differs from the pairwise order by an ulp of the sums for lists of 8 or more,
+//                        which can flip a cell whose blend lies exactly on .5.
+// No per-thread arrays: the products are accumulated while the ratings are gathered (the position of a
+// product in the sum is its neighbour index), the non-zero flags of the ratings are kept as one 64-bit mask,
+// and the weight sum walks the mask's set bits (the position of a weight in the compacted list is its rank
+// in the mask) -- so a neighbour list of up to 64 entries needs 8 accumulators, not four 64-entry arrays.
 #include "common.h"
 
 constexpr int PRED_MAXK = 64;  // longest neighbour list handled (K = round(log_1.5 n) <= 51 for n < 1e9)
 
-// numpy's float64 pairwise_sum for n <= 128 (loops_utils.h.src)
-__device__ static inline double np_sum_order(const double *a, int n) {
-  if (n < 8) {
-    double r = 0.0;
-    for (int i = 0; i < n; ++i) r += a[i];
-    return r;
+struct Pairwise8 {
+  // numpy's float64 pairwise_sum for n <= 128 (loops_utils.h.src), fed one element at a time: element t of n.
+  // n < 8: plain running sum.  Otherwise elements [0, n - n % 8) go round-robin into 8 accumulators, which
+  // are combined as ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)) when the first tail element (or the
+  // end) arrives; tail elements are then added one by one.
+  double r0, r1, r2, r3, r4, r5, r6, r7, res;
+  int n, body, t;
+  bool seq;
+  __device__ void begin(int n_, bool sequential) {
+    n = n_;
+    seq = sequential || n_ < 8;
+    body = n_ - (n_ % 8);
+    t = 0;
+    r0 = r1 = r2 = r3 = r4 = r5 = r6 = r7 = 0.0;
+    res = 0.0;
   }
-  double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
-  int i = 8;
-  for (; i < n - (n % 8); i += 8) {
-    r0 += a[i]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3];
-    r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7];
+  __device__ void add(double v) {
+    if (seq) {
+      res += v;
+    } else if (t < body) {
+      const bool first = t < 8;
+      switch (t & 7) {
+        case 0: r0 = first ? v : r0 + v; break;
+        case 1: r1 = first ? v : r1 + v; break;
+        case 2: r2 = first ? v : r2 + v; break;
+        case 3: r3 = first ? v : r3 + v; break;
+        case 4: r4 = first ? v : r4 + v; break;
+        case 5: r5 = first ? v : r5 + v; break;
+        case 6: r6 = first ? v : r6 + v; break;
+        default: r7 = first ? v : r7 + v; break;
+      }
+      if (t + 1 == body) res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    } else {
+      res += v;
+    }
+    ++t;
   }
-  double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-  for (; i < n; ++i) res += a[i];
-  return res;
-}
+  __device__ double end() const { return res; }
+};
 
-// weighted_average (recommender.py:36-47): rating[k] = the user's / query's rating of neighbour k
-__device__ static inline double weighted_average(const int32_t *rating, const double *sims, int n) {
-  double prod[PRED_MAXK], w[PRED_MAXK];
-  int nw = 0;
+// weighted_average (recommender.py:36-47) over a neighbour list of n entries: rating(k) = the user's / query's
+// rating of neighbour k, sim(k) its similarity.  RatingAt / SimAt are callables (gathers).
+template <typename RatingAt, typename SimAt>
+__device__ static inline double weighted_average(int n, bool sequential, RatingAt rating, SimAt sim) {
+  if (n == 0) return 0.0;
+  Pairwise8 prod;
+  prod.begin(n, sequential);
+  unsigned long long nz = 0;
   for (int k = 0; k < n; ++k) {
-    prod[k] = (double)rating[k] * sims[k];
-    if (rating[k] != 0) w[nw++] = sims[k];
+    const int32_t r = rating(k);
+    prod.add((double)r * sim(k));
+    if (r != 0) nz |= 1ull << k;
   }
-  const double wsum = np_sum_order(w, nw);
+  Pairwise8 w;
+  w.begin(__popcll(nz), sequential);
+  while (nz) {
+    const int k = __ffsll((long long)nz) - 1;
+    w.add(sim(k));
+    nz &= nz - 1;
+  }
+  const double wsum = w.end();
   if (wsum == 0.0) return 0.0;
-  return np_sum_order(prod, n) / wsum;
+  return prod.end() / wsum;
 }
 
 __global__ __launch_bounds__(256) void predict_kernel(const int32_t *__restrict__ ratings, int64_t nu, int64_t nq,
@@ -50,7 +97,10 @@ __global__ __launch_bounds__(256) void predict_kernel(const int32_t *__restrict_
                                                       const double *__restrict__ q_val,
                                                       const int32_t *__restrict__ u_idx,
                                                       const double *__restrict__ u_val, int ku, double qw, double uw,
-                                                      double dmean, int32_t *__restrict__ out) {
+                                                      double dmean, int sequential, int32_t *__restrict__ out) {
+  // consecutive lanes = consecutive queries of ONE user: the user-side gathers ratings[u][j] are coalesced
+  // across the wave and the user's neighbour list is wave-uniform; the query-side gathers stay inside the
+  // user's own row (4 nq bytes, cache-resident while the row's workgroups run)
   const int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (cell >= nu * nq) return;
   const int64_t i = cell / nq, j = cell - i * nq;
@@ -59,27 +109,19 @@ __global__ __launch_bounds__(256) void predict_kernel(const int32_t *__restrict_
     out[cell] = own;
     return;
   }
-  int32_t rt[PRED_MAXK];
-  double sv[PRED_MAXK];
   // query side: neighbours of query j, this user's ratings of them
   const int64_t lo = q_off[j];
-  int n = (int)(q_off[j + 1] - lo);
-  if (n > PRED_MAXK) n = PRED_MAXK;
-  for (int k = 0; k < n; ++k) {
-    rt[k] = ratings[i * nq + q_idx[lo + k]];
-    sv[k] = q_val[lo + k];
-  }
-  const double qp = weighted_average(rt, sv, n);
-  // user side: neighbours of user i, their ratings of query j
+  const int n = (int)(q_off[j + 1] - lo);   // <= PRED_MAXK: checked by the host
+  const int32_t *row = ratings + i * nq;
+  const double qp = weighted_average(
+      n, sequential != 0, [&](int k) { return row[q_idx[lo + k]]; }, [&](int k) { return q_val[lo + k]; });
+  // user side: neighbours of user i (-1 padded), their ratings of query j
+  const int32_t *ui = u_idx + i * ku;
+  const double *uv = u_val + i * ku;
   int m = 0;
-  for (int k = 0; k < ku && k < PRED_MAXK; ++k) {
-    const int32_t u = u_idx[i * ku + k];
-    if (u < 0) break;  // -1 padding
-    rt[m] = ratings[(int64_t)u * nq + j];
-    sv[m] = u_val[i * ku + k];
-    ++m;
-  }
-  const double up = weighted_average(rt, sv, m);
+  while (m < ku && ui[m] >= 0) ++m;
+  const double up = weighted_average(
+      m, sequential != 0, [&](int k) { return ratings[(int64_t)ui[k] * nq + j]; }, [&](int k) { return uv[k]; });
   double r;
   if (up == 0.0 && qp == 0.0) r = 0.0;
   else if (up == 0.0) r = qp * (qw + (uw * 0.5)) + dmean * (uw * 0.5);
@@ -88,17 +130,35 @@ __global__ __launch_bounds__(256) void predict_kernel(const int32_t *__restrict_
   out[cell] = (int32_t)rint(r);
 }
 
+// longest query neighbour list (host pre-check of the 64-entry limit without a read-back: the kernel below
+// raises a device flag, the caller reads it together with the result)
+__global__ __launch_bounds__(256) void predict_check_kernel(const int64_t *__restrict__ q_off, int64_t nq,
+                                                            uint32_t *__restrict__ too_long) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < nq && q_off[j + 1] - q_off[j] > PRED_MAXK) atomicOr(too_long, 1u);
+}
+
 QRLSH_EXPORT int qrlsh_predict(const int32_t *ratings, int64_t nu, int64_t nq, const int64_t *q_off,
                                const int32_t *q_idx, const double *q_val, const int32_t *u_idx, const double *u_val,
                                int32_t ku, double query_weight, double user_weight, double default_mean,
-                               int32_t *out, void *stream) {
-  QR_CHECK_ARG(nu >= 0 && nq >= 0 && ku >= 0 && ku <= PRED_MAXK, "qrlsh_predict: bad sizes nu=%lld nq=%lld ku=%d",
-               (long long)nu, (long long)nq, ku);
+                               int32_t sum_order, int32_t *out, uint32_t *too_long_out, void *stream) {
+  QR_CHECK_ARG(nu >= 0 && nq >= 0 && ku >= 0 && ku <= PRED_MAXK, "qrlsh_predict: bad sizes nu=%lld nq=%lld ku=%d (<= %d)",
+               (long long)nu, (long long)nq, ku, PRED_MAXK);
+  QR_CHECK_ARG(sum_order == QRLSH_SUM_PAIRWISE || sum_order == QRLSH_SUM_SEQUENTIAL, "qrlsh_predict: bad sum_order %d",
+               sum_order);
+  QR_CHECK_ARG(too_long_out, "qrlsh_predict: too_long_out is required");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(too_long_out, 0, sizeof(uint32_t), st) != hipSuccess) {
+    qrlsh_set_error("qrlsh_predict: hipMemsetAsync failed");
+    return QRLSH_EHIP;
+  }
   if (nu == 0 || nq == 0) return QRLSH_OK;
   QR_CHECK_ARG(ratings && q_off && out && (ku == 0 || (u_idx && u_val)), "qrlsh_predict: null pointer");
-  QR_LAUNCH("predict", predict_kernel, dim3((unsigned)ceil_div64(nu * nq, 256)), dim3(256), 0,
-            static_cast<hipStream_t>(stream), ratings, nu, nq, q_off, q_idx, q_val, u_idx, u_val, ku, query_weight,
-            user_weight, default_mean, out);
+  QR_LAUNCH("predict_check", predict_check_kernel, dim3((unsigned)ceil_div64(nq, 256)), dim3(256), 0, st, q_off, nq,
+            too_long_out);
+  QR_LAUNCH("predict", predict_kernel, dim3((unsigned)ceil_div64(nu * nq, 256)), dim3(256), 0, st, ratings, nu, nq,
+            q_off, q_idx, q_val, u_idx, u_val, ku, query_weight, user_weight, default_mean,
+            (int)(sum_order == QRLSH_SUM_SEQUENTIAL), out);
   QR_LAUNCH_CHECK("qrlsh_predict");
   return QRLSH_OK;
 }

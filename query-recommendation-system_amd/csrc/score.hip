@@ -30,7 +30,8 @@ __global__ __launch_bounds__(256) void score_pairs_kernel(const SigT *__restrict
                                                           uint64_t *__restrict__ edges, int id_bits,
                                                           uint32_t *__restrict__ edge_dst,
                                                           const SigT *__restrict__ sig_b,
-                                                          const int64_t *__restrict__ norm2_b, uint32_t split) {
+                                                          const int64_t *__restrict__ norm2_b, uint32_t split,
+                                                          int rev_only) {
   constexpr bool IS16 = sizeof(SigT) == 2;
   constexpr int VEC = IS16 ? 8 : 4;
   const int lane = threadIdx.x & (WAVE - 1);
@@ -85,7 +86,14 @@ __global__ __launch_bounds__(256) void score_pairs_kernel(const SigT *__restrict
       if (cosv) cosv[t] = cs;
       if (edges) {
         const uint64_t inv = (uint64_t)(1000 - mi);
-        if (edge_dst) {  // wide ids: src << 11 | inv in the key, dst as the payload
+        if (rev_only) {  // only the reverse edge (src = j), one word per pair: the select form of the top-K
+          if (edge_dst) {
+            edges[t] = ((uint64_t)j << 11) | inv;
+            edge_dst[t] = i;
+          } else {
+            edges[t] = ((uint64_t)j << (id_bits + 11)) | (inv << id_bits) | i;
+          }
+        } else if (edge_dst) {  // wide ids: src << 11 | inv in the key, dst as the payload
           edges[2 * t] = ((uint64_t)i << 11) | inv;
           edges[2 * t + 1] = ((uint64_t)j << 11) | inv;
           edge_dst[2 * t] = j;
@@ -101,7 +109,8 @@ __global__ __launch_bounds__(256) void score_pairs_kernel(const SigT *__restrict
 
 static int score_launch(const void *sig, const void *sig_b, int64_t split, int32_t sig_dtype, const int64_t *norm2,
                         const int64_t *norm2_b, int32_t P, const uint64_t *pairs, int64_t n, int32_t *milli_out,
-                        double *cos_out, uint64_t *edge_out, int32_t id_bits, uint32_t *edge_dst_out, void *stream) {
+                        double *cos_out, uint64_t *edge_out, int32_t id_bits, uint32_t *edge_dst_out, void *stream,
+                        int rev_only = 0) {
   const int64_t groups_per_block = 256 / SCORE_LPP;
   int64_t blocks = ceil_div64(n, groups_per_block);
   if (blocks > 256 * 32) blocks = 256 * 32;  // grid-stride beyond 32 workgroups per CU
@@ -113,18 +122,18 @@ static int score_launch(const void *sig, const void *sig_b, int64_t split, int32
     const uint16_t *s16 = static_cast<const uint16_t *>(sig), *s16b = static_cast<const uint16_t *>(sig_b);
     if (aligned && P % 8 == 0)
       QR_LAUNCH("score_pairs", (score_pairs_kernel<uint16_t, true>), grid, block, 0, st, s16, norm2, P, pairs, n, milli_out,
-                cos_out, edge_out, id_bits, edge_dst_out, s16b, norm2_b, sp);
+                cos_out, edge_out, id_bits, edge_dst_out, s16b, norm2_b, sp, rev_only);
     else
       QR_LAUNCH("score_pairs", (score_pairs_kernel<uint16_t, false>), grid, block, 0, st, s16, norm2, P, pairs, n, milli_out,
-                cos_out, edge_out, id_bits, edge_dst_out, s16b, norm2_b, sp);
+                cos_out, edge_out, id_bits, edge_dst_out, s16b, norm2_b, sp, rev_only);
   } else {
     const int32_t *s32 = static_cast<const int32_t *>(sig), *s32b = static_cast<const int32_t *>(sig_b);
     if (aligned && P % 4 == 0)
       QR_LAUNCH("score_pairs", (score_pairs_kernel<int32_t, true>), grid, block, 0, st, s32, norm2, P, pairs, n, milli_out,
-                cos_out, edge_out, id_bits, edge_dst_out, s32b, norm2_b, sp);
+                cos_out, edge_out, id_bits, edge_dst_out, s32b, norm2_b, sp, rev_only);
     else
       QR_LAUNCH("score_pairs", (score_pairs_kernel<int32_t, false>), grid, block, 0, st, s32, norm2, P, pairs, n, milli_out,
-                cos_out, edge_out, id_bits, edge_dst_out, s32b, norm2_b, sp);
+                cos_out, edge_out, id_bits, edge_dst_out, s32b, norm2_b, sp, rev_only);
   }
   QR_LAUNCH_CHECK("qrlsh_score_pairs");
   return QRLSH_OK;
@@ -142,6 +151,22 @@ QRLSH_EXPORT int qrlsh_score_pairs(const void *sig, int32_t sig_dtype, const int
   QR_CHECK_ARG(!edge_dst_out || edge_out, "qrlsh_score_pairs: edge_dst_out needs edge_out");
   return score_launch(sig, nullptr, 1ll << 32, sig_dtype, norm2, nullptr, P, pairs, n, milli_out, cos_out, edge_out,
                       id_bits, edge_dst_out, stream);
+}
+
+// Scores + the REVERSE edge word of every pair only (rev_out[t] = j << (id_bits + 11) | inv << id_bits | i, or
+// with rev_dst_out the key + payload form j << 11 | inv, i): the input of qrlsh_topk_select_* once sorted on j.
+QRLSH_EXPORT int qrlsh_score_pairs_rev(const void *sig, int32_t sig_dtype, const int64_t *norm2, int32_t P,
+                                       const uint64_t *pairs, int64_t n, int32_t *milli_out, uint64_t *rev_out,
+                                       int32_t id_bits, uint32_t *rev_dst_out, void *stream) {
+  QR_CHECK_ARG(n >= 0 && P > 0, "qrlsh_score_pairs_rev: bad sizes n=%lld P=%d", (long long)n, P);
+  QR_CHECK_ARG(sig_dtype == QRLSH_SIG_I32 || sig_dtype == QRLSH_SIG_U16, "qrlsh_score_pairs_rev: bad sig_dtype %d",
+               sig_dtype);
+  if (n == 0) return QRLSH_OK;
+  QR_CHECK_ARG(sig && norm2 && pairs && milli_out && rev_out, "qrlsh_score_pairs_rev: null pointer");
+  QR_CHECK_ARG(rev_dst_out || (id_bits > 0 && id_bits <= 26),
+               "qrlsh_score_pairs_rev: id_bits=%d must be in [1,26] without rev_dst_out", id_bits);
+  return score_launch(sig, nullptr, 1ll << 32, sig_dtype, norm2, nullptr, P, pairs, n, milli_out, nullptr, rev_out, id_bits,
+                      rev_dst_out, stream, 1);
 }
 
 // The same scores against a row table that comes in two pieces: row index x < split_rows is row x of

@@ -24,6 +24,8 @@ SORT_IOTA = 2
 SORT_FOLD = 4
 SORT_OWNER = 8
 SORT_HOST = 16
+SUM_PAIRWISE = 0
+SUM_SEQUENTIAL = 1
 
 _vp = ctypes.c_void_p
 _i32 = ctypes.c_int32
@@ -56,6 +58,9 @@ SIGNATURES = {
     "qrlsh_row_unique_workspace_bytes": (_sz, [_i64]),
     "qrlsh_row_unique_count": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _sz, _vp, _vp]),
     "qrlsh_row_unique_fill": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp]),
+    "qrlsh_region_unique_workspace_bytes": (_sz, [_i64, _i32]),
+    "qrlsh_region_unique_count": (ctypes.c_int, [_vp, _i64, _i32, _i32, _i64, _vp, _vp, _sz, _vp, _vp]),
+    "qrlsh_region_unique_fill": (ctypes.c_int, [_vp, _i64, _i32, _i64, _vp, _vp, _vp]),
     "qrlsh_unique_count": (ctypes.c_int, [_vp, _i64, _vp, _sz, _vp, _vp]),
     "qrlsh_unique_fill": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp]),
     "qrlsh_row_norms": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp]),
@@ -66,6 +71,10 @@ SIGNATURES = {
     "qrlsh_topk_count": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _sz, _vp, _vp]),
     "qrlsh_topk_fill": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "qrlsh_topk_fill_based": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "qrlsh_score_pairs_rev": (ctypes.c_int, [_vp, _i32, _vp, _i32, _vp, _i64, _vp, _vp, _i32, _vp, _vp]),
+    "qrlsh_topk_select_workspace_bytes": (_sz, [_i64]),
+    "qrlsh_topk_select_count": (ctypes.c_int, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _sz, _vp, _vp]),
+    "qrlsh_topk_select_fill": (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "qrlsh_idset_workspace_bytes": (_sz, [_i64]),
     "qrlsh_idset_build": (ctypes.c_int, [_vp, _i64, _i64, _i64, _i64, _i64, _i32, _vp, _sz, _vp, _vp]),
     "qrlsh_idset_list": (ctypes.c_int, [_vp, _i64, _vp, _vp]),
@@ -78,7 +87,8 @@ SIGNATURES = {
     "qrlsh_answer_sets_sweep": (ctypes.c_int, [_vp, _i64, _i64, _vp, _i64, _i32, _vp, _vp, _vp]),
     "qrlsh_answer_sets_compact": (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "qrlsh_predict": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i32, ctypes.c_double, ctypes.c_double,
-                                     ctypes.c_double, _vp, _vp]),
+                                     ctypes.c_double, _i32, _vp, _vp, _vp]),
+    "qrlsh_center_rows": (ctypes.c_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "qrlsh_prof_enable": (ctypes.c_int, [ctypes.c_int]),
     "qrlsh_prof_pause": (ctypes.c_int, [ctypes.c_int]),
     "qrlsh_prof_report": (ctypes.c_int, [ctypes.c_char_p, _sz]),

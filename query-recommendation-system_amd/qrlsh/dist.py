@@ -70,14 +70,9 @@ class HipBackend:
         g, _ = ops.sort_u64(pairs, None, host_shard=nql)
         return g, ops.owner_bounds(g, -1, nql, world)
 
-    def sort_unique(self, words, ib):
-        g = ops.row_group_bits(ib, words.numel() / max(1, self.rows_hint or 1))
-        grouped, _ = ops.sort_u64(words, None, 32 + g, 32 + ib)  # by i >> g only; rows are finished in LDS
-        pairs = ops.row_unique(grouped, g, ib)
-        if pairs is None:                                        # a row too long for the LDS image
-            words, _ = ops.sort_u64(grouped, None, 0, 2 * ib, fold=ib)
-            pairs = ops.unique_sorted(words)
-        return pairs
+    def sort_unique(self, words, nids):
+        # the words a rank receives touch ~2 x its own share of the ids (the other endpoint of half its pairs)
+        return ops.unique_pairs(words, nids, words_per_query=words.numel() / max(1, 2 * (self.rows_hint or 1)))
 
     def remote_ids(self, pairs, q0, nql, nids, world):
         return ops.remote_ids(pairs, q0, nql, nids, world)
@@ -281,7 +276,9 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
     ranges = band_owner_ranges(b, world)
     lo, hi = ranges[rank]
     nb = hi - lo
-    if exchange == "all_gather":
+    if world == 1:
+        recv, owned = keys, None  # nothing to exchange: the local keys are the [1][b][nql] buffer
+    elif exchange == "all_gather":
         allk = torch.empty((world * b, nql), dtype=torch.int64, device=dev)
         _all_gather(allk, keys, group)
         owned = allk.view(world, b, nql)[:, lo:hi, :].permute(1, 0, 2).reshape(nb, nids).contiguous()
@@ -330,7 +327,7 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
         got = emitted
     del emitted
     ph.done("4_pair_exchange")
-    pairs = be.sort_unique(got, ib) if got.numel() else got
+    pairs = be.sort_unique(got, nids) if got.numel() else got
     del got
     ph.done("4_pair_unique")
 

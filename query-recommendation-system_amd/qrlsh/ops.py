@@ -318,14 +318,57 @@ def row_unique(grouped, group_bits=0, id_bits=32):
     return out
 
 
-def unique_pairs(emitted, nq, stats=None):
-    """the Python set of lsh.py:41,53: sorted unique words of the emitted pairs (consumed)"""
+def region_group_bits(id_bits, nids, words_per_query=0.0):
+    """group bits of the region form of the de-duplication (regions of 2^g consecutive queries finished by one
+    workgroup each): as many as fit the 32-bit (i's low bits, j) value, at most 8, fewer while a region would
+    hold more than ~16 K words; None when fewer than 3 remain (single-i rows: use row_unique)"""
+    g = min(8, 32 - id_bits, id_bits)    # (no more than the id has: everything is one region then)
+    if g + id_bits == 32 and nids >= (1 << id_bits):
+        g -= 1
+    while g > 0 and words_per_query * (1 << g) > 16384:
+        g -= 1
+    return g if g >= 3 else None
+
+
+def region_unique(grouped, group_bits, id_bits, nids):
+    """Sorted unique pairs from pairs grouped by i >> group_bits (group_pairs_by_i), one workgroup per region of
+    2^group_bits queries; None when a region holds more than ~11 K distinct pairs (use the general path)."""
+    lib = _lib.load()
+    _need(grouped, torch.int64, "grouped", 1)
+    n = grouped.numel()
+    if n == 0:
+        return grouped
+    dev = grouped.device
+    tmp = torch.empty_like(grouped)
+    ws = _ws(lib.qrlsh_region_unique_workspace_bytes(nids, group_bits), dev)
+    tot = torch.empty(2, dtype=torch.int64, device=dev)
+    _lib.check(lib.qrlsh_region_unique_count(_ptr(grouped), n, int(group_bits), int(id_bits), int(nids), _ptr(tmp), _ptr(ws),
+                                             ws.numel(), _ptr(tot), _stream()))
+    total, overflow = tot.tolist()
+    if overflow:
+        return None
+    out = torch.empty((total,), dtype=torch.int64, device=dev)
+    _lib.check(lib.qrlsh_region_unique_fill(_ptr(tmp), n, int(group_bits), int(nids), _ptr(ws), _ptr(out), _stream()))
+    return out
+
+
+def unique_pairs(emitted, nq, stats=None, words_per_query=None):
+    """the Python set of lsh.py:41,53: sorted unique words of the emitted pairs (consumed).
+    words_per_query: emitted words per query id of the id space (default: emitted / nq)"""
     ib = id_bits_for(nq)
-    g = row_group_bits(ib, emitted.numel() / max(nq, 1))
-    grouped = group_pairs_by_i(emitted, nq, g)
-    pairs = row_unique(grouped, g, ib)
+    wpq = emitted.numel() / max(nq, 1) if words_per_query is None else words_per_query
+    g = region_group_bits(ib, nq, wpq)
+    if g is not None:
+        grouped = group_pairs_by_i(emitted, nq, g)
+        pairs = region_unique(grouped, g, ib, nq)
+        path = "regions-in-lds"
+    else:
+        g = row_group_bits(ib, wpq)
+        grouped = group_pairs_by_i(emitted, nq, g)
+        pairs = row_unique(grouped, g, ib)
+        path = "rows-in-lds"
     if stats is not None:
-        stats["dedup_path"] = "rows-in-lds" if pairs is not None else "full-sort"
+        stats["dedup_path"] = path if pairs is not None else "full-sort"
         stats["group_bits"] = g
     if pairs is None:
         pairs = unique_sorted(sort_pairs(grouped, nq))
@@ -602,6 +645,60 @@ def topk_edges_local(edges, edst, K, id_bits, q0, nql):
     val = torch.empty((m,), dtype=torch.int32, device=dev)
     _lib.check(lib.qrlsh_topk_fill_based(_ptr(se), None, n, K, id_bits, int(q0), _ptr(ws), _ptr(src), _ptr(dst),
                                          _ptr(val), _stream()))
+    return src, dst, val
+
+
+def score_pairs_rev(sig, norm2, pairs, id_bits, wide=None):
+    """milli per pair + the reverse edge word of every pair (src = j): -> (milli int32, rev) with rev the packed
+    int64 [n] words, or with wide ids the tuple (keys int64 [n], dst int32 [n]).  Input of topk_select."""
+    lib = _lib.load()
+    _need(sig, sig.dtype, "sig", 2)
+    _need(norm2, torch.int64, "norm2", 1)
+    _need(pairs, torch.int64, "pairs", 1)
+    n, dev = pairs.numel(), sig.device
+    if wide is None:
+        wide = wide_ids(id_bits)
+    milli = torch.empty((n,), dtype=torch.int32, device=dev)
+    rev = torch.empty((n,), dtype=torch.int64, device=dev)
+    rdst = torch.empty((n,), dtype=torch.int32, device=dev) if wide else None
+    code = _lib.SIG_U16 if sig.dtype == torch.int16 else _lib.SIG_I32
+    _lib.check(lib.qrlsh_score_pairs_rev(_ptr(sig), code, _ptr(norm2), sig.shape[1], _ptr(pairs), n, _ptr(milli), _ptr(rev),
+                                         0 if wide else int(id_bits), _ptr(rdst), _stream()))
+    return milli, ((rev, rdst) if wide else rev)
+
+
+SELECT_MAX_K = 256   # SEL_MAXK in csrc/pairs.hip
+
+
+def topk_select(pairs, milli, rev, K, id_bits, nq):
+    """Per-query top-K (recommender.py:206-210) from the sorted scored pairs and their reverse words
+    (score_pairs_rev): the reverse words are sorted on j's bits only, then every directed edge ranks itself
+    inside its query's two runs.  -> (src, dst, milli) int32, the same COO topk_edges returns."""
+    lib = _lib.load()
+    rdst = None
+    if isinstance(rev, tuple):
+        rev, rdst = rev
+    dev = pairs.device
+    n = pairs.numel()
+    if n == 0:
+        z = torch.empty((0,), dtype=torch.int32, device=dev)
+        return z, z.clone(), z.clone()
+    if K > SELECT_MAX_K:
+        raise ValueError("topk_select handles K <= %d; use topk_edges (the sort form) beyond" % SELECT_MAX_K)
+    if rdst is None:
+        rs, rd = sort_u64(rev, None, id_bits + 11, 2 * id_bits + 11)
+    else:
+        rs, rd = sort_u64(rev, rdst, 11, 11 + id_bits)
+    ws = _ws(lib.qrlsh_topk_select_workspace_bytes(nq), dev)
+    total = torch.zeros(1, dtype=torch.int64, device=dev)
+    _lib.check(lib.qrlsh_topk_select_count(_ptr(pairs), n, _ptr(rs), _ptr(rd), int(nq), K, int(id_bits), _ptr(ws), ws.numel(),
+                                           _ptr(total), _stream()))
+    m = int(total.item())
+    src = torch.empty((m,), dtype=torch.int32, device=dev)
+    dst = torch.empty((m,), dtype=torch.int32, device=dev)
+    val = torch.empty((m,), dtype=torch.int32, device=dev)
+    _lib.check(lib.qrlsh_topk_select_fill(_ptr(pairs), _ptr(milli), n, _ptr(rs), _ptr(rd), int(nq), K, int(id_bits), _ptr(ws),
+                                          _ptr(src), _ptr(dst), _ptr(val), _stream()))
     return src, dst, val
 
 

@@ -51,7 +51,7 @@ class HotPathResult:
         return ops.sig_to_int32(self.sig)
 
 
-def query_similarities(offsets, rows, table, b, K, timings=None, compact=None, wide_ids=None):
+def query_similarities(offsets, rows, table, b, K, timings=None, compact=None, wide_ids=None, topk="select"):
     """Whole hot path for the queries described by (offsets, rows) on offsets.device.
 
     table: ops.PermTable (transposed permutations).  Returns HotPathResult; `timings`, when a
@@ -80,10 +80,18 @@ def query_similarities(offsets, rows, table, b, K, timings=None, compact=None, w
     del keys
     t0 = tick("candidates", t0)
     ib = ops.id_bits_for(nq)
-    milli, _, edges = ops.score_pairs(sig, norm2, pairs, edge_id_bits=ib, wide=wide_ids)
-    t0 = tick("scoring", t0)
-    src, dst, val = ops.topk_edges(edges, K, ib)
+    if topk == "select" and K > ops.SELECT_MAX_K:
+        topk = "sort"
+    if topk == "select":     # reverse edges sorted on j alone, every edge ranks itself in its query's two runs
+        milli, rev = ops.score_pairs_rev(sig, norm2, pairs, ib, wide=wide_ids)
+        t0 = tick("scoring", t0)
+        src, dst, val = ops.topk_select(pairs, milli, rev, K, ib, nq)
+    else:                    # "sort": all 2n directed edge keys sorted on (src, value)
+        milli, _, edges = ops.score_pairs(sig, norm2, pairs, edge_id_bits=ib, wide=wide_ids)
+        t0 = tick("scoring", t0)
+        src, dst, val = ops.topk_edges(edges, K, ib)
     tick("topk", t0)
+    stats["topk"] = topk
     stats["unique_pairs"] = int(pairs.numel())
     stats["kept_edges"] = int(src.numel())
     return HotPathResult(sig, norm2, pairs, milli, src, dst, val, K, b, stats)

@@ -13,12 +13,21 @@ USER_WEIGHT = 0.4
 DEFAULT_MEAN = 60
 
 
+MAX_NEIGHBOURS = 64   # PRED_MAXK in csrc/predict.hip
+
+
 def fill_predictions(ratings, q_src, q_dst, q_milli, user_sims, query_weight=QUERY_WEIGHT,
-                     user_weight=USER_WEIGHT, default_mean=DEFAULT_MEAN, device="cuda"):
+                     user_weight=USER_WEIGHT, default_mean=DEFAULT_MEAN, device="cuda", sum_order="pairwise"):
     """ratings: (nu, nq) integer array / tensor, 0 = missing.
     q_src/q_dst/q_milli: the hot path's top-K COO (sorted by src; value = milli / 1000).
     user_sims: {u: {'indexes', 'values'}} as compute_userSimilarities returns it.
-    -> int32 device tensor (nu, nq): finalPredictions of recommender.py:301-331."""
+    sum_order: "pairwise" (numpy's np.sum order: the reference as plain Python, what the fixtures pin) or
+    "sequential" (numba's nopython np.sum: the reference where numba is installed; unpinned).
+    -> int32 device tensor (nu, nq): finalPredictions of recommender.py:301-331.
+    Raises ValueError when a neighbour list is longer than 64 (K = round(log_1.5 n) stays below 52 for any
+    n < 1e9; only an overridden max_candidates gets there)."""
+    if sum_order not in ("pairwise", "sequential"):
+        raise ValueError("sum_order must be 'pairwise' or 'sequential'")
     lib = _lib.load()
     r = torch.as_tensor(np.ascontiguousarray(np.asarray(ratings), dtype=np.int32)) if not isinstance(ratings, torch.Tensor) else ratings.to(torch.int32)
     r = r.to(device).contiguous()
@@ -30,6 +39,8 @@ def fill_predictions(ratings, q_src, q_dst, q_milli, user_sims, query_weight=QUE
     q_idx = q_dst.to(device).to(torch.int32).contiguous()
     q_val = (q_milli.to(device).to(torch.float64) / 1000.0).contiguous()
     ku = max((len(user_sims[u]["indexes"]) for u in user_sims), default=0)
+    if ku > MAX_NEIGHBOURS:
+        raise ValueError("a user has %d neighbours; the prediction kernel handles at most %d" % (ku, MAX_NEIGHBOURS))
     ui = np.full((nu, max(ku, 1)), -1, dtype=np.int32)
     uv = np.zeros((nu, max(ku, 1)), dtype=np.float64)
     for u in range(nu):
@@ -40,7 +51,12 @@ def fill_predictions(ratings, q_src, q_dst, q_milli, user_sims, query_weight=QUE
     u_idx = torch.from_numpy(ui).to(device)
     u_val = torch.from_numpy(uv).to(device)
     out = torch.empty((nu, nq), dtype=torch.int32, device=device)
+    too_long = torch.zeros((1,), dtype=torch.int32, device=device)
     _lib.check(lib.qrlsh_predict(_ptr(r), nu, nq, _ptr(q_off), _ptr(q_idx), _ptr(q_val), _ptr(u_idx), _ptr(u_val),
                                  ui.shape[1] if ku else 0, float(query_weight), float(user_weight), float(default_mean),
-                                 _ptr(out), _stream()))
+                                 _lib.SUM_SEQUENTIAL if sum_order == "sequential" else _lib.SUM_PAIRWISE,
+                                 _ptr(out), _ptr(too_long), _stream()))
+    if int(too_long.item()):
+        raise ValueError("a query has more than %d neighbours (max_candidates overridden?); the prediction kernel "
+                         "handles at most %d" % (MAX_NEIGHBOURS, MAX_NEIGHBOURS))
     return out

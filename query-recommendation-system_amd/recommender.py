@@ -163,40 +163,23 @@ class Recommender:
         self._log("\n" + str(round(time.time() - queryTime, 3)) + "s for overall queries_similarity scores")
         return query_sim
 
-    # ---- N4: user similarity (host; the reference's own sklearn pipeline) -----------
+    # ---- N4: user similarity (clustering = the reference's sklearn call on the host; the rest on the device) ----
     def compute_userSimilarities(self):
-        """{u: {'indexes', 'values'}} (recommender.py:216-290): StandardScaler -> PCA -> BIRCH, then
-        centred cosine inside each cluster, top round(log_1.5 nu) per user."""
-        from sklearn.cluster import Birch
-        from sklearn.decomposition import PCA
-        from sklearn.metrics.pairwise import cosine_similarity
-        from sklearn.preprocessing import StandardScaler
+        """{u: {'indexes', 'values'}} (recommender.py:216-290): StandardScaler -> PCA -> BIRCH (scikit-learn, as
+        in the reference), then on the device the centred cosine inside each cluster (with the reference's
+        integer truncation of the centred rows) and the top round(log_1.5 nu) per user.  Entries of value 0
+        (the user itself, negative cosines) that the reference keeps when a cluster is small are left out: they
+        weigh nothing in weighted_average."""
+        from qrlsh import users
         t0 = time.time()
         nu = self.usersIDs.size
         top = round(math.log(nu, 1.5))
         n_clusters = round(nu ** (1 / 1.3))
         self._log("\nMax user candidates: {}, Total users: {}".format(top, nu))
-        feats = StandardScaler().fit_transform(self.ratings)
-        feats = PCA(n_components=min(feats.shape[0], feats.shape[1], 200)).fit(feats).transform(feats)
         self._log("\nCluster count: {}, Total users: {}".format(n_clusters, nu))
-        label = Birch(n_clusters=n_clusters).fit(feats).predict(feats)
-        sizes = np.bincount(label)
-        label[np.isin(label, np.flatnonzero(sizes == 1))] = n_clusters     # pool the singletons (:259-261)
-        user_sim = {}
-        for c in np.unique(label):
-            members = np.flatnonzero(label == c)
-            # the reference centres the rows inside an INTEGER copy of the ratings (:268-272):
-            # the centred values are truncated toward zero, and parity needs the same
-            rows = self.ratings[members].astype(self.ratings.dtype, copy=True)
-            for k in range(rows.shape[0]):
-                rated = rows[k] != 0
-                rows[k][rated] = rows[k][rated] - np.mean(rows[k][rated])
-            sim = np.around(cosine_similarity(rows), 3)
-            np.fill_diagonal(sim, 0)
-            sim[sim < 0] = 0
-            for local, u in enumerate(members):
-                best = np.argsort(sim[local])[::-1][:top]
-                user_sim[int(u)] = {"indexes": members[best], "values": sim[local][best]}
+        label = users.cluster_labels(self.ratings)
+        src, dst, val = users.user_similarities(self.ratings, label, top, self.device)
+        user_sim = users.sims_to_dict(src, dst, val, nu)
         self._log("\n" + str(round(time.time() - t0, 3)) + "s for overall users_similarity scores")
         return user_sim
 

@@ -5,7 +5,7 @@ import numpy as np
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
-FULL = ["cfg1_hotpath", "cfg1b_hotpath", "full_p180", "full_p160", "full_p320", "full_p200", "full_p160_wrap", "full_p160_ties",
+FULL = ["cfg1_hotpath", "cfg1b_hotpath", "cfg2_hotpath", "full_p180", "full_p160", "full_p320", "full_p200", "full_p160_wrap", "full_p160_ties",
         "full_p100_r5", "full_p50_r5_wrap"]   # the last two: wide bands (r = 5), the reference's pick for PERM = 100 / 50
 PIECES = ["pieces_p128_b32", "pieces_p256_b64", "pieces_p128_b32_wrap", "pieces_p96_b12"]   # last: r = 8
 
@@ -87,7 +87,8 @@ def recall_at_k(ref_src, ref_dst, ref_val, src, dst, val, k=10):
     return hit / max(tot, 1)
 
 
-GENERATOR_SETS = ["cfg1", "cfg1b"]   # two data sets written by the reference's resources/generator.py (different seeds)
+GENERATOR_SETS = ["cfg1", "cfg1b", "cfg2"]   # data sets written by the reference's resources/generator.py: its default sizes
+                                             # with two seeds, and 700 rows x 150 queries x 60 users
 
 
 def generator_table_and_queries(sub):

@@ -187,6 +187,64 @@ def test_row_unique_equals_sorted_set(case, id_bits):
             assert got is not None and np.array_equal(u64(got), np.unique(words)), g
 
 
+@pytest.mark.parametrize("case,id_bits,g", [("short", 20, 8), ("short", 24, 8), ("mixed", 20, 8), ("mixed", 24, 7),
+                                             ("hot", 20, 8), ("hot", 24, 8), ("big", 20, 8), ("big", 24, 6), ("short", 27, 5),
+                                             ("short", 29, 3),
+                                             ("sparse", 24, 8), ("one", 20, 8), ("empty", 20, 8)])
+def test_region_unique_equals_sorted_set(case, id_bits, g):
+    """qrlsh_region_unique_* (one workgroup per 2^g consecutive queries, LDS hash set + per-i placement) ==
+    np.unique of the same words; the words only need to be ordered by i >> g"""
+    rng = np.random.default_rng(21)
+    nids = min((1 << id_bits) - 1, 3_000_000)
+    nrows = 30000
+    if case == "short":
+        lens = rng.poisson(17, size=nrows)
+    elif case == "mixed":
+        lens = rng.poisson(12, size=nrows)
+        lens[rng.integers(0, nrows, size=60)] = rng.integers(300, 3000, size=60)
+    elif case == "hot":        # single queries with tens of thousands of emitted words, few of them distinct
+        lens = rng.poisson(9, size=nrows)
+        lens[[0, 777, 778, nrows - 1]] = [40000, 25000, 18000, 30000]
+    elif case == "big":        # queries with 7 - 11 thousand DISTINCT partners: the big-image kernel's regions
+        lens = rng.poisson(9, size=nrows)
+        lens[[5, 300, 900, 9000, nrows - 2]] = [84000, 100000, 90000, 130000, 120000]
+    elif case == "sparse":     # most regions empty
+        lens = np.zeros(nrows, dtype=np.int64)
+        lens[rng.integers(0, nrows, size=300)] = rng.integers(1, 200, size=300)
+    elif case == "one":
+        lens = np.array([900])
+    else:
+        lens = np.array([], dtype=np.int64)
+    words = _rows_case(rng, len(lens), lens, nids, dup=12 if case in ("hot", "big") else 4)
+    words = words[rng.permutation(len(words))]
+    grouped = words[np.argsort(words >> np.uint64(32 + g), kind="stable")]     # by region only
+    got = ops.region_unique(dev(grouped.view(np.int64)), g, id_bits, nids)
+    assert got is not None
+    assert np.array_equal(u64(got), np.unique(words))
+
+
+def test_region_unique_reports_overflow_and_unique_pairs_falls_back():
+    rng = np.random.default_rng(22)
+    lens = rng.poisson(10, size=3000)
+    lens[1500] = 60000                    # one i with ~15000 DISTINCT partners: more than even the big image holds
+    words = _rows_case(rng, len(lens), lens, 1 << 20, dup=4)
+    grouped = words[np.argsort(words >> np.uint64(40), kind="stable")]
+    assert ops.region_unique(dev(grouped.view(np.int64)), 8, 20, 1 << 20) is None
+    stats = {}
+    got = ops.unique_pairs(dev(words[rng.permutation(len(words))].view(np.int64)), (1 << 20) - 1, stats)
+    assert stats["dedup_path"] == "full-sort" and np.array_equal(u64(got), np.unique(words))
+    stats = {}
+    lens[1500] = 10
+    words = _rows_case(rng, len(lens), lens, 1 << 20, dup=3)
+    got = ops.unique_pairs(dev(words[rng.permutation(len(words))].view(np.int64)), (1 << 20) - 1, stats)
+    assert stats["dedup_path"] == "regions-in-lds" and stats["group_bits"] == 8
+    assert np.array_equal(u64(got), np.unique(words))
+    # id widths that leave no room for group bits keep the single-i rows
+    stats = {}
+    got = ops.unique_pairs(dev(words[rng.permutation(len(words))].view(np.int64)), (1 << 31) - 1, stats)
+    assert stats["dedup_path"] == "rows-in-lds" and np.array_equal(u64(got), np.unique(words))
+
+
 def test_row_unique_reports_overflow_and_unique_pairs_falls_back():
     rng = np.random.default_rng(12)
     lens = rng.poisson(10, size=3000)
@@ -195,13 +253,13 @@ def test_row_unique_reports_overflow_and_unique_pairs_falls_back():
     assert ops.row_unique(dev(words.view(np.int64))) is None
     shuffled = words[rng.permutation(len(words))]
     stats = {}
-    got = ops.unique_pairs(dev(shuffled.view(np.int64)), 1 << 20, stats)
+    got = ops.unique_pairs(dev(shuffled.view(np.int64)), 1 << 31, stats)     # 32-bit ids: the single-i row form
     assert stats["dedup_path"] == "full-sort"
     assert np.array_equal(u64(got), np.unique(words))
     stats = {}
     lens[1500] = 10
     words = _rows_case(rng, len(lens), lens, 1 << 20, dup=3)
-    got = ops.unique_pairs(dev(words[rng.permutation(len(words))].view(np.int64)), 1 << 20, stats)
+    got = ops.unique_pairs(dev(words[rng.permutation(len(words))].view(np.int64)), 1 << 31, stats)
     assert stats["dedup_path"] == "rows-in-lds" and np.array_equal(u64(got), np.unique(words))
 
 
@@ -460,7 +518,7 @@ def test_full_size_config3_equals_oracle():
     perms = ops.legacy_permutations(P, D, seed=42)
     res = pipeline.query_similarities(off, rows, ops.perm_table(perms, DEV), b, K)
     torch.cuda.synchronize()
-    assert res.stats["bucket_path"] == "partition+lds" and res.stats["dedup_path"] == "rows-in-lds"
+    assert res.stats["bucket_path"] == "partition+lds" and res.stats["dedup_path"] == "regions-in-lds"
     assert res.stats["part_bits"] == 12
     O.set_threads(16)
     _check_against_oracle(res, off, rows, perms, b, K, nq)
@@ -595,7 +653,7 @@ def test_sharded_driver_wide_ids_beyond_2_pow_26(tmp_path):
     """config-5-sized id space through the SHARDED driver on the device: nq_total > 2^26 (key + payload
     edges, re-based to 64-bit local keys on arrival), more than 2^24 records per owned band (BIGID
     partition reading the exchanged key layout in place), two gloo ranks sharing the GPU."""
-    nq, D, P, b, world = 68_000_000, 32768, 4, 2, 2
+    nq, D, P, b, world = 68_000_000, 32768, 8, 2, 2       # r = 4: buckets stay small (r = 2 keys collide in the thousands)
     outs = _run_dist_gpu(tmp_path, world, nq, D, P, b, "all_to_all", "gloo", 29597, "fetch", mean=4.0)
     K = pipeline.max_candidates(nq)
     off, rows = qrlsh.synth_csr(nq, D, seed=0, mean=4.0, device=DEV)
@@ -808,18 +866,64 @@ def test_wide_id_edge_format_gives_the_same_topk():
     off, rows = qrlsh.synth_csr(nq, D, seed=0, device=DEV)
     table = ops.perm_table(ops.legacy_permutations(P, D, seed=42), DEV)
     a = pipeline.query_similarities(off, rows, table, b, K)
-    w = pipeline.query_similarities(off, rows, table, b, K, wide_ids=True)
     torch.cuda.synchronize()
-    assert torch.equal(a.src, w.src) and torch.equal(a.dst, w.dst) and torch.equal(a.val, w.val)
+    for kw in (dict(wide_ids=True), dict(topk="sort"), dict(topk="sort", wide_ids=True)):
+        w = pipeline.query_similarities(off, rows, table, b, K, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(a.src, w.src) and torch.equal(a.dst, w.dst) and torch.equal(a.val, w.val), kw
+        assert torch.equal(a.milli, w.milli)
     assert not ops.wide_ids(26) and ops.wide_ids(27)
+
+
+@pytest.mark.parametrize("K", [1, 3, 40])
+def test_topk_select_form_equals_sort_form_and_numpy(K):
+    """qrlsh_topk_select_* (reverse words sorted on j, every edge ranks itself in its query's two runs) ==
+    qrlsh_topk_* on all directed edge keys == a numpy lexsort, on pair lists with heavy value ties, very
+    popular queries (thousands of neighbours) and queries without any"""
+    rng = np.random.default_rng(7 + K)
+    nq = 60000
+    i = rng.integers(0, nq - 1, size=300000)
+    j = rng.integers(0, nq, size=300000)
+    hot = rng.integers(0, nq, size=20000)
+    i = np.concatenate([i, np.full(20000, 777), hot[:9000], rng.integers(0, 50, size=5000)])      # 777 and 31000: popular
+    j = np.concatenate([j, hot, np.full(9000, 31000), rng.integers(0, 50, size=5000)])
+    keep = i != j
+    lo, hi = np.minimum(i, j)[keep], np.maximum(i, j)[keep]
+    pairs = np.unique((lo.astype(np.uint64) << np.uint64(32)) | hi.astype(np.uint64))
+    n = len(pairs)
+    milli = rng.integers(990, 1001, size=n).astype(np.int32)          # few distinct values: ties everywhere
+    milli[rng.integers(0, n, size=n // 10)] = rng.integers(-1000, 1001, size=n // 10)
+    ib = ops.id_bits_for(nq)
+    pi, pj = (pairs >> np.uint64(32)).astype(np.int64), (pairs & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    src = np.concatenate([pi, pj]); dst = np.concatenate([pj, pi]); val = np.concatenate([milli, milli]).astype(np.int64)
+    o = np.lexsort((dst, -val, src))
+    src, dst, val = src[o], dst[o], val[o]
+    first = np.r_[0, np.flatnonzero(src[1:] != src[:-1]) + 1]
+    pos = np.arange(len(src)) - np.repeat(first, np.diff(np.r_[first, len(src)]))
+    sel = pos < K
+    dp, dm = dev(pairs.view(np.int64)), dev(milli)
+    inv = (1000 - milli).astype(np.uint64)
+    for wide in (False, True):
+        if wide:
+            rev = (dev(((pj.astype(np.uint64) << np.uint64(11)) | inv).view(np.int64)), dev(pi.astype(np.int32)))
+        else:
+            rev = dev(((pj.astype(np.uint64) << np.uint64(ib + 11)) | (inv << np.uint64(ib)) | pi.astype(np.uint64)).view(np.int64))
+        s1, d1, v1 = (t.cpu().numpy() for t in ops.topk_select(dp, dm, rev, K, ib, nq))
+        assert np.array_equal(s1, src[sel]) and np.array_equal(d1, dst[sel]) and np.array_equal(v1, val[sel])
+    e = ops.pair_edges_interleaved(dp, dm, ib)
+    s2, d2, v2 = (t.cpu().numpy() for t in ops.topk_edges(e, K, ib))
+    assert np.array_equal(s2, src[sel]) and np.array_equal(d2, dst[sel]) and np.array_equal(v2, val[sel])
+    z = ops.topk_select(dp[:0], dm[:0], dev(np.zeros(0, np.int64)), K, ib, nq)
+    assert all(t.numel() == 0 for t in z)
 
 
 # ---------------------------------------------------------------------------- N1 / N3 / N4
 @pytest.mark.parametrize("sub", GENERATOR_SETS)
 def test_compute_scores_dropin_matches_reference_on_generator_default_inputs(sub):
-    """main.py's flow on the generator-default CSVs through the drop-in Recommender: pandas
-    ingest (N3), device answer sets (N2), hot path, sklearn user similarity (N4), device
-    prediction loop (N1) -> the reference's finalPredictions, cell for cell."""
+    """main.py's flow on the generator's CSVs (cfg1 / cfg1b: its defaults, two seeds; cfg2: 60 users x 150
+    queries) through the drop-in Recommender: pandas ingest (N3), device answer sets (N2), hot path, user
+    similarity (N4: scikit-learn clustering on the host, centred cosine + cut on the device), device prediction
+    loop (N1) -> the reference's finalPredictions, cell for cell."""
     import pandas as pd
     import recommender as R
     g = load(sub + "_scores")
@@ -845,28 +949,119 @@ def test_compute_scores_dropin_matches_reference_on_generator_default_inputs(sub
     rec.top_k_queries(to_predict, final, missed, ask=lambda prompt: next(answers))
 
 
+def _check_user_sims_tie_aware(mine, ref, K):
+    """mine / ref: {u: {'indexes', 'values'}}.  The reference keeps zero-valued entries (the user itself, negative
+    cosines) when a cluster has fewer than K positive neighbours and orders ties arbitrarily (np.argsort); the
+    device lists hold the positive entries only, ties by ascending id.  Equal means: same positive value
+    multiset per user, every device neighbour strictly above the cut-off value is a reference neighbour and
+    vice versa."""
+    assert sorted(mine.keys()) == sorted(ref.keys())
+    for u in ref:
+        rv = np.asarray(ref[u]["values"], dtype=np.float64)
+        ri = np.asarray(ref[u]["indexes"])
+        pos = rv > 0
+        mv, mi = np.asarray(mine[u]["values"]), np.asarray(mine[u]["indexes"])
+        assert len(mv) <= K and np.all(mv > 0) and np.all(np.diff(mv) <= 0)
+        assert np.array_equal(np.sort(mv), np.sort(rv[pos])), u
+        if len(mv):
+            cut = mv.min()
+            assert set(mi[mv > cut].tolist()) == set(ri[pos & (rv > cut)].tolist()), u
+        for a, b, x, y in zip(mi[:-1], mi[1:], mv[:-1], mv[1:]):
+            assert x > y or a < b
+
+
+@pytest.mark.parametrize("sub", GENERATOR_SETS)
+def test_device_user_similarity_matches_reference(sub):
+    """N4 (recommender.py:263-288) on the device -- integer-truncated centring, cosine of every pair of users of
+    a cluster, per-user cut -- against the reference's own compute_userSimilarities output (golden) and the
+    oracle restatement, with the cluster labels of the reference's scikit-learn call"""
+    from qrlsh import users
+    g = load(sub + "_scores")
+    ratings = g["ratings"]
+    nu = ratings.shape[0]
+    K = users.max_candidates(nu)
+    labels = O.user_cluster_labels(ratings)
+    assert np.array_equal(labels, users.cluster_labels(ratings))
+    src, dst, val = users.user_similarities(ratings, labels, K, DEV)
+    mine = users.sims_to_dict(src, dst, val, nu)
+    gold = {u: {"indexes": g["us_idx"][u][g["us_idx"][u] >= 0], "values": g["us_val"][u][g["us_idx"][u] >= 0]}
+            for u in range(nu)}
+    _check_user_sims_tie_aware(mine, gold, K)
+    _check_user_sims_tie_aware(mine, O.user_similarities_from_labels(ratings, labels), K)
+    # the centred rows themselves: truncation toward zero, zeros untouched
+    c = users.center_rows(dev(ratings.astype(np.int32))).cpu().numpy()[:, :ratings.shape[1]]
+    ref = ratings.astype(np.int64).copy()
+    for r in ref:
+        nz = r != 0
+        if nz.any():
+            r[nz] = r[nz] - np.mean(r[nz])
+    assert np.array_equal(c, ref)
+
+
+def test_device_user_similarity_on_random_clusters():
+    """larger, synthetic: 3000 users in clusters of 1 .. 400, 257 queries (row stride padding), ratings with
+    rows of a single distinct value (zero norm after centring) and empty rows"""
+    from qrlsh import users
+    rng = np.random.default_rng(44)
+    nu, nq = 3000, 257
+    ratings = (rng.integers(1, 101, size=(nu, nq)) * (rng.random((nu, nq)) < 0.3)).astype(np.int64)
+    ratings[5] = 0
+    ratings[6] = 0
+    ratings[6, :40] = 77
+    labels = rng.integers(0, 60, size=nu)
+    labels[:400] = 1000
+    labels[401] = 2000                                   # a cluster of one
+    K = users.max_candidates(nu)
+    src, dst, val = users.user_similarities(ratings, labels, K, DEV)
+    _check_user_sims_tie_aware(users.sims_to_dict(src, dst, val, nu), O.user_similarities_from_labels(ratings, labels), K)
+
+
+def _random_prediction_case(rng, nu, nq, Kq, Ku, fill):
+    ratings = (rng.integers(1, 101, size=(nu, nq)) * (rng.random((nu, nq)) < fill)).astype(np.int64)
+    qs, src, dst, mil = {}, [], [], []
+    for j in range(nq):
+        if rng.random() < 0.8:
+            n = int(rng.integers(1, Kq + 1))
+            idx = rng.choice(nq, size=min(n, nq), replace=False)
+            v = np.sort(rng.integers(0, 1001, size=len(idx)))[::-1]
+            qs[j] = {"indexes": idx.astype(np.int64), "values": v / 1000.0}
+            src += [j] * len(idx); dst += idx.tolist(); mil += v.tolist()
+    us = {}
+    for u in range(nu):
+        n = int(rng.integers(1, Ku + 1))
+        idx = rng.choice(nu, size=min(n, nu), replace=False)
+        us[u] = {"indexes": idx.astype(np.int64), "values": np.sort(rng.integers(0, 1001, size=len(idx)))[::-1] / 1000.0}
+    coo = (torch.tensor(src, dtype=torch.int32), torch.tensor(dst, dtype=torch.int32), torch.tensor(mil, dtype=torch.int32))
+    return ratings, qs, us, coo
+
+
 def test_prediction_kernel_equals_oracle_on_random_inputs():
+    """N1 (recommender.py:36-47, 301-331): the kernel against the oracle restatement in BOTH summation orders
+    -- numpy's pairwise sum (the reference as plain Python: what the cfg1 fixtures pin) and the sequential one
+    (numba's np.sum: the reference with numba installed, no fixture possible here) -- on lists up to the
+    64-entry limit; longer lists are refused, not truncated."""
     from qrlsh import predict
+
+    def seq_sum(a):
+        r = 0.0
+        for v in a:
+            r += float(v)
+        return r
     rng = np.random.default_rng(12)
-    for (nu, nq, Kq, Ku, fill) in [(7, 9, 3, 2, 0.5), (40, 60, 17, 11, 0.3), (25, 30, 20, 12, 0.8), (5, 5, 1, 1, 0.0)]:
-        ratings = (rng.integers(1, 101, size=(nu, nq)) * (rng.random((nu, nq)) < fill)).astype(np.int64)
-        qs, src, dst, mil = {}, [], [], []
-        for j in range(nq):
-            if rng.random() < 0.8:
-                n = int(rng.integers(1, Kq + 1))
-                idx = rng.choice(nq, size=min(n, nq), replace=False)
-                v = np.sort(rng.integers(0, 1001, size=len(idx)))[::-1]
-                qs[j] = {"indexes": idx.astype(np.int64), "values": v / 1000.0}
-                src += [j] * len(idx); dst += idx.tolist(); mil += v.tolist()
-        us = {}
-        for u in range(nu):
-            n = int(rng.integers(1, Ku + 1))
-            idx = rng.choice(nu, size=min(n, nu), replace=False)
-            us[u] = {"indexes": idx.astype(np.int64), "values": np.sort(rng.integers(0, 1001, size=len(idx)))[::-1] / 1000.0}
-        ref = O.predict_scores(ratings, qs, us)
-        out = predict.fill_predictions(ratings, torch.tensor(src, dtype=torch.int32), torch.tensor(dst, dtype=torch.int32),
-                                       torch.tensor(mil, dtype=torch.int32), us, device=DEV)
-        assert np.array_equal(out.cpu().numpy(), ref)
+    for (nu, nq, Kq, Ku, fill) in [(7, 9, 3, 2, 0.5), (40, 60, 17, 11, 0.3), (25, 30, 20, 12, 0.8), (5, 5, 1, 1, 0.0),
+                                   (70, 90, 64, 64, 0.6), (33, 80, 41, 7, 0.9)]:
+        ratings, qs, us, coo = _random_prediction_case(rng, nu, nq, Kq, Ku, fill)
+        out = predict.fill_predictions(ratings, *coo, us, device=DEV)
+        assert np.array_equal(out.cpu().numpy(), O.predict_scores(ratings, qs, us))
+        out = predict.fill_predictions(ratings, *coo, us, device=DEV, sum_order="sequential")
+        assert np.array_equal(out.cpu().numpy(), O.predict_scores(ratings, qs, us, summation=seq_sum))
+    ratings, qs, us, coo = _random_prediction_case(rng, 80, 100, 80, 10, 0.5)
+    assert max(len(v["indexes"]) for v in qs.values()) > 64
+    with pytest.raises(ValueError, match="more than 64 neighbours"):
+        predict.fill_predictions(ratings, *coo, us, device=DEV)
+    ratings, qs, us, coo = _random_prediction_case(rng, 80, 100, 10, 80, 0.5)
+    with pytest.raises(ValueError, match="at most 64"):
+        predict.fill_predictions(ratings, *coo, us, device=DEV)
 
 
 def test_answer_sets_one_sweep_equals_count_then_fill():

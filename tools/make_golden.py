@@ -19,7 +19,7 @@ How the reference is run:
 
 Usage:  python tools/make_golden.py            (rewrites the round-1 base fixtures)
         python tools/make_golden.py NAME...    (only the named later additions: full_p100_r5,
-                                                full_p50_r5_wrap, pieces_p96_b12, cfg1_scores, cfg1b)
+                                                full_p50_r5_wrap, pieces_p96_b12, cfg1_scores, cfg1b, cfg2)
 """
 import os
 import sys
@@ -237,8 +237,9 @@ def synth_csr(nq, D, seed, cluster=8, mean=16, p_replace=0.15, n_empty=0, n_dup=
 
 
 # --------------------------------------------------------------------------
-def fixture_generator_default(recommender_mod, lsh_mod, sub="cfg1", gen_seed=20250114, name="cfg1_hotpath"):
-    """config 1: resources/generator.py defaults -> 4 CSVs -> reference hot path."""
+def fixture_generator_default(recommender_mod, lsh_mod, sub="cfg1", gen_seed=20250114, name="cfg1_hotpath", sizes=None):
+    """config 1: resources/generator.py defaults -> 4 CSVs -> reference hot path.
+    sizes = (MAX_DATA, MAX_QUERIES, MAX_USERS) overrides the generator's module constants (generator.py:14-16)."""
     scratch = tempfile.mkdtemp(prefix="qr_gen_")
     try:
         shutil.copytree(os.path.join(REF, "resources", "input"), os.path.join(scratch, "input"))
@@ -250,6 +251,8 @@ def fixture_generator_default(recommender_mod, lsh_mod, sub="cfg1", gen_seed=202
         for attr, empty in (("user_tastes", {}), ("queries", []), ("user_queries", {}), ("usersIDs", []),
                             ("queriesIDs", [])):
             setattr(generator, attr, type(empty)())          # module-level state: start clean on a second run
+        if sizes is not None:
+            generator.MAX_DATA, generator.MAX_QUERIES, generator.MAX_USERS = sizes
         random.seed(gen_seed)
         np.random.seed(gen_seed)
         with _quiet():
@@ -460,6 +463,10 @@ def main():
         if want("cfg1b"):     # a second generator-default data set (different generator seed)
             fixture_generator_default(recommender_mod, lsh_mod, sub="cfg1b", gen_seed=7, name="cfg1b_hotpath")
             fixture_cfg1_scores(recommender_mod, lsh_mod, sub="cfg1b", name="cfg1b_scores")
+        if want("cfg2"):      # other sizes than the generator's defaults: 700 table rows, 150 queries, 60 users
+            fixture_generator_default(recommender_mod, lsh_mod, sub="cfg2", gen_seed=11, name="cfg2_hotpath",
+                                      sizes=(700, 150, 60))
+            fixture_cfg1_scores(recommender_mod, lsh_mod, sub="cfg2", name="cfg2_scores")
         if want("pieces_p96_b12"):
             fixture_pieces(recommender_mod, lsh_mod, "pieces_p96_b12", nq=500, D=3000, P=96, b=12, seed=29,
                            data_seed=10, n_empty=3, n_dup=3, p_replace=0.05)

@@ -2,8 +2,10 @@
 """Condense rocprofv3 outputs (kernel-trace stats + separate FETCH_SIZE / WRITE_SIZE PMC passes)
 into the small files committed under profiles/.
 
-usage: summarise_profile.py <tag> <trace_dir> <pmc_fetch_dir> <pmc_write_dir>
+usage: summarise_profile.py <tag> <trace_dir> <pmc_fetch_dir> <pmc_write_dir> [nq_total P b]
 writes profiles/<tag>_kernel_stats.csv, profiles/<tag>_hbm_traffic.csv, profiles/<tag>_hbm_traffic.json
+The JSON records the workload the passes ran (default: bench.py's default, 10 M x 128 / 32) and a hash of
+the kernel sources at the time of the run: bench.py quotes roofline.traffic from it only when both match.
 """
 import csv
 import glob
@@ -14,6 +16,7 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 
 def short(name):
@@ -34,7 +37,10 @@ LABELS = [
     (r"^pairs_count_kernel", "pairs_count"), (r"^pairs_fill_kernel", "pairs_fill"),
     (r"^row_unique_kernel", "row_unique"), (r"^row_unique_gather_kernel", "row_unique_gather"),
     (r"^sort_scatter_staged_kernel", "sort_scatter_k"), (r"^part_scatter_staged_kernel", "sort_scatter_kv"),
-    (r"^part_scatter_atomic_kernel", "part_scatter"),
+    (r"^part_scatter_atomic_kernel", "part_scatter"), (r"^row_unique_long_kernel", "row_unique_long"),
+    (r"^region_unique_kernel", "region_unique"), (r"^region_gather_kernel", "region_gather"),
+    (r"^region_bounds_kernel", "region_bounds"), (r"^region_unique_big_kernel", "region_unique_big"),
+    (r"^edge_bounds_kernel", "topk_bounds"), (r"^topk_len_kernel", "topk_len"), (r"^topk_select_kernel", "topk_select"),
     (r"^compact_count_kernel<0>", "unique_count"), (r"^compact_fill_kernel<0>", "unique_fill"),
     (r"^compact_count_kernel<1>", "topk_count"), (r"^compact_fill_kernel<1>", "topk_fill"),
     (r"^score_pairs_kernel", "score_pairs"), (r"^scan_u64_kernel", "scan_blocks"), (r"^synth_kernel", "synth"),
@@ -62,6 +68,8 @@ def pmc(dirname, counter):
 
 def main():
     tag, trace, fdir, wdir = sys.argv[1:5]
+    wl = [int(x) for x in sys.argv[5:8]] if len(sys.argv) >= 8 else [10_000_000, 128, 32]
+    from bench import csrc_fingerprint
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
     ks = glob.glob(os.path.join(trace, "**", "*kernel_stats.csv"), recursive=True)[0]
@@ -99,6 +107,7 @@ def main():
     for lab, e in by_label.items():
         e["hbm_bytes_per_launch"] = e.pop("bytes") / max(e["launches"], 1)
     json.dump({"by_kernel": traffic, "by_label": by_label,
+               "workload": {"nq_total": wl[0], "P": wl[1], "b": wl[2]}, "csrc_sha": csrc_fingerprint(),
                "note": "FETCH_SIZE(KB)*1024*2 (gfx950 half-count correction) + WRITE_SIZE(KB)*1024, averaged per launch; "
                        "separate rocprofv3 --pmc passes"},
               open(os.path.join(out, tag + "_hbm_traffic.json"), "w"), indent=1, sort_keys=True)
