@@ -70,7 +70,13 @@ uint64_t qrlsh_mix64_host(uint64_t x);
  *           table.  At least one of sig_out / sig16_out.  Half the bytes for qrlsh_score_pairs.
  * norm2_out [nq] int64 = sum_p sig^2 (exact), or NULL          -- feeds qrlsh_score_pairs
  * keys_out  [b][nq] uint64 band keys (see qrlsh_band_keys), or NULL -- fused a2
+ * PRECONDITION (not checked by qrlsh_minhash itself, which gathers table row rows[k] directly): offsets[0] = 0,
+ * offsets non-decreasing, offsets[nq] = nnz and 0 <= rows[k] < D.  qrlsh_check_csr tests exactly that on the
+ * device: *flags_out (device uint32) = 0 when it holds, else bit 0 = bad first / last offset, bit 1 = offsets
+ * decrease, bit 2 = a row id out of range.
  */
+int qrlsh_check_csr(const int64_t *offsets, const int32_t *rows, int64_t nq, int64_t nnz, int32_t D,
+                    uint32_t *flags_out, void *stream);
 int qrlsh_minhash(const int64_t *offsets, const int32_t *rows, int64_t nq, const void *perm_t,
                   int32_t perm_dtype, int32_t P, int32_t P_stride, int32_t D, int32_t *sig_out,
                   uint16_t *sig16_out, int64_t *norm2_out, uint64_t *keys_out, int32_t b, void *stream);

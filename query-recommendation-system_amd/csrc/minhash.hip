@@ -261,7 +261,8 @@ __global__ __launch_bounds__(256) void minhash_group_kernel(const int64_t *__res
 #pragma unroll
         for (int j = 0; j < MH_CH; ++j) {
           const int ds = group_bcast<LPR>(my, sub + j, g);
-          // 32-bit byte offset from a uniform base (table < 4 GiB, d < 2^24: checked by the host)
+          // 32-bit byte offset from a uniform base (table < 4 GiB, D <= 2^24: checked by the host; 0 <= d < D is the
+          // caller's precondition -- qrlsh_check_csr tests it, ops.minhash(validate=True) by default)
           v[j] = TabVec<TabT>::init();
           if (base + sub + j < n_cur)
             v[j] = *reinterpret_cast<const VecT *>(tbytes + (__umul24((uint32_t)ds, row_bytes) + col_bytes));
@@ -337,6 +338,34 @@ __global__ __launch_bounds__(256) void row_norms_kernel(const int32_t *__restric
     for (int m = 1; m < WAVE; m <<= 1) acc += __shfl_xor(acc, m, WAVE);
     if (lane == 0) norm2[q] = acc;
   }
+}
+
+// Precondition check of the CSR answer sets (qrlsh_minhash gathers table row rows[k] unchecked): flag bit 0 =
+// offsets[0] != 0 or offsets[nq] != nnz, bit 1 = offsets decrease somewhere, bit 2 = a row id outside [0, D).
+__global__ __launch_bounds__(256) void check_csr_kernel(const int64_t *__restrict__ offsets,
+                                                        const int32_t *__restrict__ rows, int64_t nq, int64_t nnz, int D,
+                                                        uint32_t *__restrict__ flags) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t bad = 0;
+  if (t == 0 && (offsets[0] != 0 || offsets[nq] != nnz)) bad |= 1u;
+  if (t < nq && offsets[t + 1] < offsets[t]) bad |= 2u;
+  if (t < nnz && (uint32_t)rows[t] >= (uint32_t)D) bad |= 4u;
+  if (bad) atomicOr(flags, bad);
+}
+
+QRLSH_EXPORT int qrlsh_check_csr(const int64_t *offsets, const int32_t *rows, int64_t nq, int64_t nnz, int32_t D,
+                                 uint32_t *flags_out, void *stream) {
+  QR_CHECK_ARG(nq >= 0 && nnz >= 0 && D > 0 && offsets && flags_out && (nnz == 0 || rows), "qrlsh_check_csr: bad arguments");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(flags_out, 0, sizeof(uint32_t), st) != hipSuccess) {
+    qrlsh_set_error("qrlsh_check_csr: hipMemsetAsync failed");
+    return QRLSH_EHIP;
+  }
+  const int64_t m = (nq > nnz ? nq : nnz) + 1;
+  QR_LAUNCH("check_csr", check_csr_kernel, dim3((unsigned)ceil_div64(m, 256)), dim3(256), 0, st, offsets, rows, nq, nnz, D,
+            flags_out);
+  QR_LAUNCH_CHECK("qrlsh_check_csr");
+  return QRLSH_OK;
 }
 
 static int pick_qpb(int P) {

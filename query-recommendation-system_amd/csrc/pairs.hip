@@ -719,6 +719,7 @@ QRLSH_EXPORT int qrlsh_row_unique_fill(const uint64_t *tmp, int64_t n, const voi
 constexpr int RG_THREADS = 1024;
 constexpr int RG_SEG = 6144;     // distinct pairs a region may hold
 constexpr int RG_ROWS = 256;     // 2^g <= 256
+constexpr int RG_LONGROW = 192;  // a query with more distinct neighbours than this is ranked through sub-buckets
 
 __global__ __launch_bounds__(256) void region_bounds_kernel(const uint64_t *__restrict__ w, int64_t n, int shift,
                                                             int64_t nregions, uint64_t *__restrict__ starts) {
@@ -743,6 +744,7 @@ __device__ static inline bool region_finish(const uint64_t *__restrict__ in, int
   __shared__ uint32_t tab[TAB];
   __shared__ uint32_t seg[SEG];
   __shared__ uint32_t rowcnt[RG_ROWS], rowstart[RG_ROWS + 1], rowfill[RG_ROWS];
+  __shared__ uint32_t sub[RG_ROWS], substart[RG_ROWS + 1], subfill[RG_ROWS];
   __shared__ uint32_t wsum[RG_ROWS / WAVE];
   __shared__ uint32_t full, ndist;
   const int t = threadIdx.x, lane = t & (WAVE - 1), wv = t >> 6;
@@ -830,9 +832,60 @@ __device__ static inline bool region_finish(const uint64_t *__restrict__ in, int
   for (uint32_t k = t; k < u; k += RG_THREADS) {
     const uint32_t v = seg[k], row = v >> jbits;
     const uint32_t rs = rowstart[row], re = rowstart[row + 1];
+    if (re - rs > (uint32_t)RG_LONGROW) continue;  // a popular query: below
     uint32_t r = 0;
     for (uint32_t q = rs; q < re; ++q) r += seg[q] < v;
     dst[rs + r] = (ihigh | row) << 32 | (v & jmask);
+  }
+  // A popular query (hundreds to thousands of distinct neighbours) would cost its square that way.  Its values
+  // are first dealt into 256 sub-buckets by the top bits of j (the same count -> scan -> deal as above, into the
+  // hash table's space, which is dead by now) and then ranked inside their sub-bucket.
+  const int sh = jbits > 8 ? jbits - 8 : 0;
+  uint32_t *seg2 = tab;
+  for (int row = 0; row < RG_ROWS; ++row) {  // uniform: every thread sees the same rowstart[]
+    const uint32_t rs = rowstart[row], n = rowstart[row + 1] - rs;
+    if (n <= (uint32_t)RG_LONGROW) continue;
+    __syncthreads();  // the previous long row (or the short-row loop) is done with sub* / seg2
+    if (t < RG_ROWS) {
+      sub[t] = 0;
+      subfill[t] = 0;
+    }
+    __syncthreads();
+    for (uint32_t k = t; k < n; k += RG_THREADS) atomicAdd(&sub[(seg[rs + k] & jmask) >> sh], 1u);
+    __syncthreads();
+    uint32_t c2 = 0, inc2 = 0;
+    if (t < RG_ROWS) {
+      c2 = sub[t];
+      inc2 = c2;
+#pragma unroll
+      for (int d = 1; d < WAVE; d <<= 1) {
+        const uint32_t o = __shfl_up(inc2, d, WAVE);
+        if (lane >= d) inc2 += o;
+      }
+      if (lane == WAVE - 1) wsum[wv] = inc2;
+    }
+    __syncthreads();
+    if (t < RG_ROWS) {
+      uint32_t base = 0;
+#pragma unroll
+      for (int k = 0; k < RG_ROWS / WAVE; ++k)
+        if (k < wv) base += wsum[k];
+      substart[t] = base + inc2 - c2;
+      if (t == RG_ROWS - 1) substart[RG_ROWS] = base + inc2;
+    }
+    __syncthreads();
+    for (uint32_t k = t; k < n; k += RG_THREADS) {
+      const uint32_t v = seg[rs + k], b2 = (v & jmask) >> sh;
+      seg2[substart[b2] + atomicAdd(&subfill[b2], 1u)] = v;
+    }
+    __syncthreads();
+    for (uint32_t k = t; k < n; k += RG_THREADS) {
+      const uint32_t v = seg2[k], b2 = (v & jmask) >> sh;
+      const uint32_t bs = substart[b2], be = substart[b2 + 1];
+      uint32_t r = 0;
+      for (uint32_t q = bs; q < be; ++q) r += seg2[q] < v;
+      dst[rs + bs + r] = (ihigh | (uint32_t)row) << 32 | (v & jmask);
+    }
   }
   if (t == 0) counts[region] = u;
   __syncthreads();  // the big kernel re-uses the arrays for its next region
@@ -998,9 +1051,11 @@ QRLSH_EXPORT int qrlsh_topk_fill_based(const uint64_t *sorted_edges, const uint3
 // neighbours are then two runs, [fstart[q], fstart[q+1]) of the pairs and [rstart[q], rstart[q+1]) of the sorted
 // reverse words, and every directed edge finds its rank in its query's list by counting the edges of those two
 // runs that order before it (value descending, then neighbour id ascending) -- stopping as soon as K of them
-// have been seen, so a very popular query costs ~K n log(n / K) compares, not n^2.  Edge of rank r < K goes to
-// out[off[q] + r], off = exclusive scan of min(K, list length): the output is the same (src, value desc, dst
-// asc) COO the sort form writes, bit for bit.
+// have been seen.  Edge of rank r < K goes to out[off[q] + r], off = exclusive scan of min(K, list length): the
+// output is the same (src, value desc, dst asc) COO the sort form writes, bit for bit.  Three kernels by list
+// length: up to 16 neighbours (almost every query) a 16-lane group per query ranks by rotating the keys round
+// its DPP row; 17 .. 64 a wave per query; longer lists a wave per query with a histogram of the 2001 possible
+// values (O(length), see below).
 // Reverse words: packed  j << (id_bits + 11) | inv << id_bits | i  (rdst == NULL), or key + payload
 // (j << 11 | inv, i) for ids that do not fit.
 __device__ static inline uint32_t rev_src(uint64_t w, int id_bits, bool wide) {
@@ -1018,24 +1073,58 @@ __global__ __launch_bounds__(256) void edge_bounds_kernel(const uint64_t *__rest
   for (int64_t q = p + 1; q <= s && q <= nq; ++q) start[q] = (uint32_t)t;
 }
 
-constexpr int SEL_LONG = 96;    // lists longer than this go to the wave-per-query kernel
+constexpr int SEL_SHORT = 16;   // lists up to here: one 16-lane group per query (every query is visited)
+constexpr int SEL_LONG = 64;    // lists up to here: one wave per query; beyond: the histogram kernel
 constexpr int SEL_MAXK = 256;   // largest K of the select form (the sort form has no limit)
-constexpr int SEL_LONG_GRID = 1024;
+constexpr int SEL_LIST_GRID = 1024;
 
+// list lengths -> output counts (min(K, length)); queries whose list does not fit a 16-lane group are put on
+// the medium (17 .. 64) or the long list.  A workgroup classifies LEN_QPB consecutive queries, collects its two
+// lists in LDS and reserves their room with ONE global atomic each: a popular counter word takes ~90 atomics per
+// microsecond, and at 10 M queries nearly every wave holds a medium query.
+constexpr int LEN_QPB = 4096;
 __global__ __launch_bounds__(256) void topk_len_kernel(const uint32_t *__restrict__ fstart,
                                                        const uint32_t *__restrict__ rstart, int64_t nq, int K,
-                                                       uint64_t *__restrict__ cnt, uint32_t *__restrict__ longlist,
-                                                       unsigned long long *__restrict__ nlong) {
-  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q > nq) return;
-  uint64_t c = 0;
-  if (q < nq) {
-    c = (uint64_t)(fstart[q + 1] - fstart[q]) + (rstart[q + 1] - rstart[q]);
-    if (c > (uint64_t)SEL_LONG)
-      longlist[__hip_atomic_fetch_add(nlong, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = (uint32_t)q;
-    if (c > (uint64_t)K) c = (uint64_t)K;
+                                                       uint64_t *__restrict__ cnt, uint32_t *__restrict__ medlist,
+                                                       uint32_t *__restrict__ longlist,
+                                                       unsigned long long *__restrict__ nlists) {
+  __shared__ uint32_t smed[LEN_QPB], slng[LEN_QPB];
+  __shared__ uint32_t nmed, nlng;
+  __shared__ unsigned long long bmed, blng;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  if (threadIdx.x == 0) {
+    nmed = 0;
+    nlng = 0;
   }
-  cnt[q] = c;  // one word past the end: the scan leaves the total there
+  __syncthreads();
+  const int64_t q0 = (int64_t)blockIdx.x * LEN_QPB;
+#pragma unroll 4
+  for (int it = 0; it < LEN_QPB / 256; ++it) {
+    const int64_t q = q0 + it * 256 + threadIdx.x;
+    uint64_t c = 0;
+    if (q < nq) c = (uint64_t)(fstart[q + 1] - fstart[q]) + (rstart[q + 1] - rstart[q]);
+    if (q <= nq) cnt[q] = c > (uint64_t)K ? (uint64_t)K : c;  // one word past the end (0): the scan leaves the total there
+    const bool med = c > (uint64_t)SEL_SHORT && c <= (uint64_t)SEL_LONG, lng = c > (uint64_t)SEL_LONG;
+    const uint64_t mm = __ballot(med), ml = __ballot(lng);
+    uint32_t pm = 0, pl = 0;
+    if (lane == 0) {
+      if (mm) pm = atomicAdd(&nmed, (uint32_t)__popcll(mm));
+      if (ml) pl = atomicAdd(&nlng, (uint32_t)__popcll(ml));
+    }
+    pm = __shfl(pm, 0, WAVE);
+    pl = __shfl(pl, 0, WAVE);
+    if (med) smed[pm + (uint32_t)__popcll(mm & lt_mask)] = (uint32_t)q;
+    if (lng) slng[pl + (uint32_t)__popcll(ml & lt_mask)] = (uint32_t)q;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    bmed = nmed ? __hip_atomic_fetch_add(&nlists[0], (unsigned long long)nmed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    blng = nlng ? __hip_atomic_fetch_add(&nlists[1], (unsigned long long)nlng, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+  }
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < nmed; k += 256) medlist[bmed + k] = smed[k];
+  for (uint32_t k = threadIdx.x; k < nlng; k += 256) longlist[blng + k] = slng[k];
 }
 
 // (inv << 32 | dst) of element x of a query's list: x < nr -> reverse run, else forward run
@@ -1051,54 +1140,105 @@ __device__ static inline uint64_t sel_key(uint32_t x, uint32_t rs, uint32_t nr, 
   return (uint64_t)(uint32_t)(1000 - milli[y]) << 32 | (uint32_t)pairs[y];
 }
 
-__global__ __launch_bounds__(256) void topk_select_kernel(const uint64_t *__restrict__ pairs,
-                                                          const int32_t *__restrict__ milli, int64_t n,
-                                                          const uint64_t *__restrict__ rev,
-                                                          const uint32_t *__restrict__ rdst,
-                                                          const uint32_t *__restrict__ fstart,
-                                                          const uint32_t *__restrict__ rstart,
-                                                          const uint64_t *__restrict__ off, int K, int id_bits,
-                                                          int32_t *__restrict__ src_out, int32_t *__restrict__ dst_out,
-                                                          int32_t *__restrict__ milli_out) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= 2 * n) return;
-  const bool wide = rdst != nullptr;
+// 64-bit value of the lane S positions further round this lane's 16-lane row (DPP row_ror)
+template <int S> __device__ static inline uint64_t row_ror64(uint64_t v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x120 + S, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x120 + S, 0xF, 0xF, false);
+  return (uint64_t)(uint32_t)hi << 32 | (uint32_t)lo;
+}
+template <int S> __device__ static inline uint32_t row_rank(uint64_t mine) {
+  uint32_t r = row_ror64<S>(mine) < mine;
+  if constexpr (S > 1) r += row_rank<S - 1>(mine);
+  return r;
+}
+
+// Lists of up to 16 neighbours (almost every query): one 16-lane group per query, lane l holds element l, and a
+// lane's rank is the number of smaller keys met while the row rotates past it (15 DPP steps, no memory traffic).
+// Absent elements carry the key ~0: never smaller than a real one.
+constexpr int SEL_QPG = 4;  // queries per 16-lane group: their loads are issued together (latency-bound otherwise)
+__global__ __launch_bounds__(256) void topk_select_short_kernel(const uint64_t *__restrict__ pairs,
+                                                                const int32_t *__restrict__ milli,
+                                                                const uint64_t *__restrict__ rev,
+                                                                const uint32_t *__restrict__ rdst,
+                                                                const uint32_t *__restrict__ fstart,
+                                                                const uint32_t *__restrict__ rstart,
+                                                                const uint64_t *__restrict__ off, int64_t nq, int K,
+                                                                int id_bits, int32_t *__restrict__ src_out,
+                                                                int32_t *__restrict__ dst_out,
+                                                                int32_t *__restrict__ milli_out) {
+  const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) >> 4;
+  const uint32_t l = threadIdx.x & 15;
   const uint64_t idm = id_bits >= 32 ? 0xFFFFFFFFull : (1ull << id_bits) - 1ull;
-  uint32_t src, dst, inv;
-  if (e < n) {  // forward edge of pair e
-    const uint64_t pr = pairs[e];
-    src = (uint32_t)(pr >> 32);
-    dst = (uint32_t)pr;
-    inv = (uint32_t)(1000 - milli[e]);
-  } else {  // reverse edge
-    const uint64_t w = rev[e - n];
-    src = rev_src(w, id_bits, wide);
-    if (wide) {
-      inv = (uint32_t)(w & 0x7FFull);
-      dst = rdst[e - n];
-    } else {
-      inv = (uint32_t)((w >> id_bits) & 0x7FFull);
-      dst = (uint32_t)(w & idm);
+  // query c of this group: group + c * ngroups (consecutive groups -> consecutive queries: the start arrays are read in runs)
+  uint32_t fs[SEL_QPG], rs[SEL_QPG], nr[SEL_QPG], len[SEL_QPG];
+  uint64_t o0[SEL_QPG], mine[SEL_QPG];
+#pragma unroll
+  for (int c = 0; c < SEL_QPG; ++c) {
+    const int64_t q = group + (int64_t)c * ngroups;
+    uint32_t nf = 0;
+    fs[c] = rs[c] = nr[c] = 0;
+    o0[c] = 0;
+    if (q < nq) {
+      fs[c] = fstart[q];
+      nf = fstart[q + 1] - fs[c];
+      rs[c] = rstart[q];
+      nr[c] = rstart[q + 1] - rs[c];
+      o0[c] = off[q];
+    }
+    len[c] = nf + nr[c];
+    if (len[c] > (uint32_t)SEL_SHORT) len[c] = 0;  // another kernel's query
+  }
+#pragma unroll
+  for (int c = 0; c < SEL_QPG; ++c)
+    mine[c] = l < len[c] ? sel_key(l, rs[c], nr[c], fs[c], pairs, milli, rev, rdst, id_bits, idm) : ~0ull;
+#pragma unroll
+  for (int c = 0; c < SEL_QPG; ++c) {
+    const uint32_t rank = row_rank<15>(mine[c]);  // executed by every lane (all lanes of the wave are active here)
+    if (l < len[c] && rank < (uint32_t)K) {
+      const uint64_t o = o0[c] + rank;
+      src_out[o] = (int32_t)(group + (int64_t)c * ngroups);
+      dst_out[o] = (int32_t)(uint32_t)mine[c];
+      milli_out[o] = 1000 - (int32_t)(uint32_t)(mine[c] >> 32);
     }
   }
-  const uint64_t mine = (uint64_t)inv << 32 | dst;
-  const uint32_t fs = fstart[src], nf = fstart[src + 1] - fs, rs = rstart[src], nr = rstart[src + 1] - rs;
-  const uint32_t len = nf + nr;
-  if (len > (uint32_t)SEL_LONG) return;  // a popular query: topk_select_long_kernel
-  uint32_t rank = 0;
-  for (uint32_t x0 = 0; x0 < len && rank < (uint32_t)K; x0 += 4) {  // four independent loads in flight
-    uint64_t k[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-      k[c] = x0 + c < len ? sel_key(x0 + c, rs, nr, fs, pairs, milli, rev, rdst, id_bits, idm) : ~0ull;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) rank += k[c] < mine;
-  }
-  if (rank < (uint32_t)K) {
-    const uint64_t o = off[src] + rank;
-    src_out[o] = (int32_t)src;
-    dst_out[o] = (int32_t)dst;
-    milli_out[o] = 1000 - (int32_t)inv;
+}
+
+// Lists of 17 .. 64 neighbours: one wave per query, from a fixed grid that walks the medium list.
+__global__ __launch_bounds__(256) void topk_select_medium_kernel(const uint64_t *__restrict__ pairs,
+                                                                 const int32_t *__restrict__ milli,
+                                                                 const uint64_t *__restrict__ rev,
+                                                                 const uint32_t *__restrict__ rdst,
+                                                                 const uint32_t *__restrict__ fstart,
+                                                                 const uint32_t *__restrict__ rstart,
+                                                                 const uint64_t *__restrict__ off,
+                                                                 const uint32_t *__restrict__ medlist,
+                                                                 const unsigned long long *__restrict__ nlists, int K,
+                                                                 int id_bits, int32_t *__restrict__ src_out,
+                                                                 int32_t *__restrict__ dst_out,
+                                                                 int32_t *__restrict__ milli_out) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const uint64_t idm = id_bits >= 32 ? 0xFFFFFFFFull : (1ull << id_bits) - 1ull;
+  const unsigned long long nm = nlists[0], nwaves = (unsigned long long)gridDim.x * (blockDim.x / WAVE);
+  for (unsigned long long e = (unsigned long long)blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x >> 6); e < nm;
+       e += nwaves) {
+    const uint32_t q = medlist[e];
+    const uint32_t fs = fstart[q], nf = fstart[q + 1] - fs, rs = rstart[q], nr = rstart[q + 1] - rs;
+    const uint32_t len = nf + nr;  // 17 .. 64
+    const uint64_t mine = (uint32_t)lane < len ? sel_key(lane, rs, nr, fs, pairs, milli, rev, rdst, id_bits, idm) : ~0ull;
+    uint32_t rank = 0;
+#pragma unroll 9
+    for (int s = 1; s < WAVE; ++s) {  // every other lane's key once (absent elements: ~0, never smaller)
+      const int from = (lane + s) & (WAVE - 1);
+      const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)mine, from, WAVE), hi = (uint32_t)__shfl((int)(uint32_t)(mine >> 32), from, WAVE);
+      rank += ((uint64_t)hi << 32 | lo) < mine;
+    }
+    if ((uint32_t)lane < len && rank < (uint32_t)K) {
+      const uint64_t o = off[q] + rank;
+      src_out[o] = (int32_t)q;
+      dst_out[o] = (int32_t)(uint32_t)mine;
+      milli_out[o] = 1000 - (int32_t)(uint32_t)(mine >> 32);
+    }
   }
 }
 
@@ -1115,7 +1255,7 @@ __global__ __launch_bounds__(256) void topk_select_long_kernel(const uint64_t *_
                                                                const uint32_t *__restrict__ rstart,
                                                                const uint64_t *__restrict__ off,
                                                                const uint32_t *__restrict__ longlist,
-                                                               const unsigned long long *__restrict__ nlong, int K,
+                                                               const unsigned long long *__restrict__ nlists, int K,
                                                                int id_bits, int32_t *__restrict__ src_out,
                                                                int32_t *__restrict__ dst_out,
                                                                int32_t *__restrict__ milli_out) {
@@ -1126,7 +1266,7 @@ __global__ __launch_bounds__(256) void topk_select_long_kernel(const uint64_t *_
   uint32_t *hist = hist_all[wv];
   uint64_t *keep = keep_all[wv];
   const uint64_t idm = id_bits >= 32 ? 0xFFFFFFFFull : (1ull << id_bits) - 1ull;
-  const unsigned long long nl = *nlong;
+  const unsigned long long nl = nlists[1];
   const unsigned long long nwaves = (unsigned long long)gridDim.x * 4;
   const uint64_t lt_mask = (1ull << lane) - 1ull;
   for (unsigned long long e = (unsigned long long)blockIdx.x * 4 + wv; e < nl; e += nwaves) {
@@ -1198,9 +1338,10 @@ __global__ __launch_bounds__(256) void topk_select_long_kernel(const uint64_t *_
   }
 }
 
-// workspace: fstart u32[nq + 1] | rstart u32[nq + 1] | longlist u32[nq] | off u64[nq + 2] | nlong | chunk totals of the scan
+// workspace: fstart u32[nq + 1] | rstart u32[nq + 1] | medlist u32[nq] | longlist u32[nq] | off u64[nq + 2] |
+//            list lengths u64[2] | chunk totals of the scan
 struct SelWs {
-  uint32_t *fstart, *rstart, *longlist;
+  uint32_t *fstart, *rstart, *medlist, *longlist;
   uint64_t *off, *nlong, *sums;
   size_t bytes;
 };
@@ -1211,6 +1352,8 @@ static SelWs sel_ws(void *workspace, int64_t nq) {
   w.fstart = reinterpret_cast<uint32_t *>(p + o);
   o += ((size_t)(nq + 1) * 4 + 15) & ~(size_t)15;
   w.rstart = reinterpret_cast<uint32_t *>(p + o);
+  o += ((size_t)(nq + 1) * 4 + 15) & ~(size_t)15;
+  w.medlist = reinterpret_cast<uint32_t *>(p + o);
   o += ((size_t)(nq + 1) * 4 + 15) & ~(size_t)15;
   w.longlist = reinterpret_cast<uint32_t *>(p + o);
   o += ((size_t)(nq + 1) * 4 + 15) & ~(size_t)15;
@@ -1245,7 +1388,7 @@ QRLSH_EXPORT int qrlsh_topk_select_count(const uint64_t *pairs, int64_t n, const
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
   const SelWs w = sel_ws(workspace, nq);
-  if (hipMemsetAsync(w.nlong, 0, sizeof(uint64_t), st) != hipSuccess) {
+  if (hipMemsetAsync(w.nlong, 0, 2 * sizeof(uint64_t), st) != hipSuccess) {
     qrlsh_set_error("qrlsh_topk_select_count: hipMemsetAsync failed");
     return QRLSH_EHIP;
   }
@@ -1253,8 +1396,9 @@ QRLSH_EXPORT int qrlsh_topk_select_count(const uint64_t *pairs, int64_t n, const
   QR_LAUNCH("topk_bounds", (edge_bounds_kernel<true>), g1, blk, 0, st, pairs, n, nq, id_bits, 0, w.fstart);
   QR_LAUNCH("topk_bounds", (edge_bounds_kernel<false>), g1, blk, 0, st, rev_sorted, n, nq, id_bits, rev_dst ? 1 : 0,
             w.rstart);
-  QR_LAUNCH("topk_len", topk_len_kernel, dim3((unsigned)ceil_div64(nq + 1, 256)), blk, 0, st, (const uint32_t *)w.fstart,
-            (const uint32_t *)w.rstart, nq, K, w.off, w.longlist, reinterpret_cast<unsigned long long *>(w.nlong));
+  QR_LAUNCH("topk_len", topk_len_kernel, dim3((unsigned)ceil_div64(nq + 1, LEN_QPB)), blk, 0, st, (const uint32_t *)w.fstart,
+            (const uint32_t *)w.rstart, nq, K, w.off, w.medlist, w.longlist,
+            reinterpret_cast<unsigned long long *>(w.nlong));
   qr_scan_u64(w.off, nq + 1, total_out, w.sums, st);
   QR_LAUNCH_CHECK("qrlsh_topk_select_count");
   return QRLSH_OK;
@@ -1270,13 +1414,16 @@ QRLSH_EXPORT int qrlsh_topk_select_fill(const uint64_t *pairs, const int32_t *mi
   QR_CHECK_ARG(pairs && milli && rev_sorted && workspace && src_out && dst_out && milli_out,
                "qrlsh_topk_select_fill: null pointer");
   const SelWs w = sel_ws(const_cast<void *>(workspace), nq);
-  QR_LAUNCH("topk_select", topk_select_kernel, dim3((unsigned)ceil_div64(2 * n, 256)), dim3(256), 0,
-            static_cast<hipStream_t>(stream), pairs, milli, n, rev_sorted, rev_dst, (const uint32_t *)w.fstart,
-            (const uint32_t *)w.rstart, (const uint64_t *)w.off, K, id_bits, src_out, dst_out, milli_out);
-  QR_LAUNCH("topk_select_long", topk_select_long_kernel, dim3(SEL_LONG_GRID), dim3(256), 0,
-            static_cast<hipStream_t>(stream), pairs, milli, rev_sorted, rev_dst, (const uint32_t *)w.fstart,
-            (const uint32_t *)w.rstart, (const uint64_t *)w.off, (const uint32_t *)w.longlist,
-            (const unsigned long long *)w.nlong, K, id_bits, src_out, dst_out, milli_out);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const uint32_t *fsp = w.fstart, *rsp = w.rstart;
+  const uint64_t *offp = w.off;
+  const unsigned long long *nl = reinterpret_cast<const unsigned long long *>(w.nlong);
+  QR_LAUNCH("topk_select", topk_select_short_kernel, dim3((unsigned)ceil_div64(nq, 16 * SEL_QPG)), dim3(256), 0, st, pairs, milli,
+            rev_sorted, rev_dst, fsp, rsp, offp, nq, K, id_bits, src_out, dst_out, milli_out);
+  QR_LAUNCH("topk_select_medium", topk_select_medium_kernel, dim3(SEL_LIST_GRID), dim3(256), 0, st, pairs, milli,
+            rev_sorted, rev_dst, fsp, rsp, offp, (const uint32_t *)w.medlist, nl, K, id_bits, src_out, dst_out, milli_out);
+  QR_LAUNCH("topk_select_long", topk_select_long_kernel, dim3(SEL_LIST_GRID), dim3(256), 0, st, pairs, milli, rev_sorted,
+            rev_dst, fsp, rsp, offp, (const uint32_t *)w.longlist, nl, K, id_bits, src_out, dst_out, milli_out);
   QR_LAUNCH_CHECK("qrlsh_topk_select_fill");
   return QRLSH_OK;
 }

@@ -40,6 +40,7 @@ SIGNATURES = {
     "qrlsh_last_error": (ctypes.c_char_p, []),
     "qrlsh_mix64_host": (_u64, [_u64]),
     "qrlsh_minhash": (ctypes.c_int, [_vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "qrlsh_check_csr": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _vp]),
     "qrlsh_band_keys": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     "qrlsh_sort_workspace_bytes": (_sz, [_i64, _i32]),
     "qrlsh_sort_u64": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _u32, _u64, _vp, _sz, _vp]),

@@ -48,9 +48,11 @@ class HipBackend:
     """libqrlsh kernels (the product path)."""
 
     rows_hint = 0   # queries this rank owns (set by the driver): sizes the rows of the pair de-dup
+    validate = True  # check the answer sets before MinHash gathers by their row ids (ops.check_csr)
 
     def minhash(self, offsets, rows, table, b):
-        return ops.minhash(offsets, rows, table, b=b, want_norm=True, compact=ops.can_compact(table))
+        return ops.minhash(offsets, rows, table, b=b, want_norm=True, compact=ops.can_compact(table),
+                           validate=self.validate)
 
     def emit_pairs(self, keys, r):
         return ops.emit_pairs_any(keys, r)

@@ -108,17 +108,35 @@ def sig_to_int32(sig):
     return torch.where(v == 0xFFFF, torch.full_like(v, -1), v)
 
 
-def minhash(offsets, rows, table, b=None, want_norm=True, compact=False):
+def check_csr(offsets, rows, D):
+    """raise ValueError unless (offsets, rows) is a well-formed CSR of row ids in [0, D): the kernel gathers
+    table rows by these ids without a bounds check (one small kernel + one read-back)"""
+    lib = _lib.load()
+    nq = offsets.numel() - 1
+    flags = torch.zeros((1,), dtype=torch.int32, device=offsets.device)
+    _lib.check(lib.qrlsh_check_csr(_ptr(offsets), _ptr(rows), nq, rows.numel(), int(D), _ptr(flags), _stream()))
+    f = int(flags.item())
+    if f:
+        what = [m for bit, m in ((1, "offsets[0] != 0 or offsets[-1] != len(rows)"), (2, "offsets decrease"),
+                                 (4, "row id outside [0, %d)" % D)) if f & bit]
+        raise ValueError("malformed answer sets: " + "; ".join(what))
+
+
+def minhash(offsets, rows, table, b=None, want_norm=True, compact=False, validate=True):
     """sig[q][p] = min over the answer set of perm_p (recommender.py:105-143), -1 if empty.
     Returns (sig [nq,P], norm2 int64 [nq] | None, keys int64 [b,nq] | None).  sig is int32, or
     with compact=True (needs can_compact(table)) the uint16 rows (torch.int16 bit patterns,
-    0xFFFF = -1) that qrlsh_score_pairs reads at half the bytes; see sig_to_int32."""
+    0xFFFF = -1) that qrlsh_score_pairs reads at half the bytes; see sig_to_int32.
+    validate: check the CSR first (check_csr); callers that built it with the library's own kernels
+    (answer_sets, synth_csr) may pass False."""
     lib = _lib.load()
     _need(offsets, torch.int64, "offsets", 1)
     _need(rows, torch.int32, "rows", 1)
     nq = offsets.numel() - 1
     if nq < 0:
         raise ValueError("offsets must have nq+1 entries")
+    if validate and nq > 0:
+        check_csr(offsets, rows, table.D)
     P = table.P
     dev = offsets.device
     if b is not None and P % b != 0:
@@ -377,7 +395,8 @@ def unique_pairs(emitted, nq, stats=None, words_per_query=None):
 
 def part_bits_for(n):
     """T = bits of the hash partition of the fast bucket path: parts of <= ~4400 records on
-    average (the LDS image holds 6144), at least 8, at most 16."""
+    average (the LDS image holds 6144; the room above the mean is for popular keys -- with parts of ~4900
+    on average the 10 M-query bench workload overflows a part), at least 8, at most 16."""
     t = 8
     while t < 16 and n > 4400 * (1 << t):
         t += 1

@@ -51,11 +51,13 @@ class HotPathResult:
         return ops.sig_to_int32(self.sig)
 
 
-def query_similarities(offsets, rows, table, b, K, timings=None, compact=None, wide_ids=None, topk="select"):
+def query_similarities(offsets, rows, table, b, K, timings=None, compact=None, wide_ids=None, topk="select",
+                       validate=True):
     """Whole hot path for the queries described by (offsets, rows) on offsets.device.
 
     table: ops.PermTable (transposed permutations).  Returns HotPathResult; `timings`, when a
     dict, receives per-phase wall seconds (each phase synchronised -- diagnostic use only).
+    validate: check the answer sets first (ops.check_csr: the MinHash kernel gathers by row id unchecked).
     """
     nq = offsets.numel() - 1
     P = table.P
@@ -74,14 +76,14 @@ def query_similarities(offsets, rows, table, b, K, timings=None, compact=None, w
     t0 = time.perf_counter() if timings is not None else 0.0
     if compact is None:
         compact = ops.can_compact(table)   # uint16 signature rows whenever they are lossless
-    sig, norm2, keys = ops.minhash(offsets, rows, table, b=b, want_norm=True, compact=compact)
+    sig, norm2, keys = ops.minhash(offsets, rows, table, b=b, want_norm=True, compact=compact, validate=validate)
     t0 = tick("signatures", t0)
     pairs = ops.candidate_pairs(keys, r, stats, sig=sig)
     del keys
     t0 = tick("candidates", t0)
     ib = ops.id_bits_for(nq)
-    if topk == "select" and K > ops.SELECT_MAX_K:
-        topk = "sort"
+    if topk == "select" and (K > ops.SELECT_MAX_K or pairs.numel() >= (1 << 31)):
+        topk = "sort"      # the select form's limits (csrc/pairs.hip: SEL_MAXK, 32-bit run starts)
     if topk == "select":     # reverse edges sorted on j alone, every edge ranks itself in its query's two runs
         milli, rev = ops.score_pairs_rev(sig, norm2, pairs, ib, wide=wide_ids)
         t0 = tick("scoring", t0)

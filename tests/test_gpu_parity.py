@@ -88,6 +88,16 @@ def test_minhash_empty_input_and_errors():
         ops.minhash(dev(np.zeros(2, np.int64)), dev(np.zeros(0, np.int32)), table, b=3)
     with pytest.raises(ValueError):           # wide bands need the signatures for verification
         ops.candidate_pairs(dev(np.zeros((2, 4), np.int64)), 5)
+    # malformed answer sets are refused before the kernel gathers by their row ids (D = 16 here)
+    good_off, good_rows = np.array([0, 2, 2, 5], np.int64), np.array([3, 15, 0, 7, 9], np.int32)
+    ops.minhash(dev(good_off), dev(good_rows), table, b=4)
+    for off, rows, what in [(good_off, np.array([3, 16, 0, 7, 9], np.int32), "row id outside"),
+                            (good_off, np.array([3, -1, 0, 7, 9], np.int32), "row id outside"),
+                            (np.array([0, 3, 2, 5], np.int64), good_rows, "offsets decrease"),
+                            (np.array([1, 2, 2, 5], np.int64), good_rows, "offsets\\[0\\]"),
+                            (np.array([0, 2, 2, 4], np.int64), good_rows, "offsets\\[-1\\]")]:
+        with pytest.raises(ValueError, match=what):
+            ops.minhash(dev(off), dev(rows), table, b=4)
 
 
 # ---------------------------------------------------------------------------- sort
@@ -509,7 +519,7 @@ def _check_against_oracle(res, off, rows, perms, b, K, nq):
 
 def test_full_size_config3_equals_oracle():
     """BASELINE configs[2] = SURVEY config 3 (10 M queries, P=128, b=32, one GPU): the workload bench.py
-    times.  Two-step partition (T = 12), long rows through the one-row-per-workgroup kernel; signatures,
+    times.  Two-step partition (T > 8), popular queries through the big-image and histogram kernels; signatures,
     candidate pairs, scores and top-K are compared exactly with the oracle (16 s on the box's host cores)."""
     nq, D, P, b = 10_000_000, 32768, 128, 32
     K = pipeline.max_candidates(nq)
@@ -519,7 +529,7 @@ def test_full_size_config3_equals_oracle():
     res = pipeline.query_similarities(off, rows, ops.perm_table(perms, DEV), b, K)
     torch.cuda.synchronize()
     assert res.stats["bucket_path"] == "partition+lds" and res.stats["dedup_path"] == "regions-in-lds"
-    assert res.stats["part_bits"] == 12
+    assert res.stats["part_bits"] > 8                         # two-step partition
     O.set_threads(16)
     _check_against_oracle(res, off, rows, perms, b, K, nq)
     del res
@@ -598,6 +608,8 @@ def test_wide_ids_beyond_2_pow_26_queries():
 def _run_dist_gpu(tmp_path, world, nq, D, P, b, mode, backend, port, sig_mode="auto", mean=16.0):
     import subprocess
     import sys as _sys
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()     # the ranks share this process's GPU: give back what earlier tests left cached
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
     env["OMP_NUM_THREADS"] = "1"
@@ -654,9 +666,9 @@ def test_sharded_driver_wide_ids_beyond_2_pow_26(tmp_path):
     edges, re-based to 64-bit local keys on arrival), more than 2^24 records per owned band (BIGID
     partition reading the exchanged key layout in place), two gloo ranks sharing the GPU."""
     nq, D, P, b, world = 68_000_000, 32768, 8, 2, 2       # r = 4: buckets stay small (r = 2 keys collide in the thousands)
-    outs = _run_dist_gpu(tmp_path, world, nq, D, P, b, "all_to_all", "gloo", 29597, "fetch", mean=4.0)
+    outs = _run_dist_gpu(tmp_path, world, nq, D, P, b, "all_to_all", "gloo", 29597, "fetch")
     K = pipeline.max_candidates(nq)
-    off, rows = qrlsh.synth_csr(nq, D, seed=0, mean=4.0, device=DEV)
+    off, rows = qrlsh.synth_csr(nq, D, seed=0, device=DEV)
     res = pipeline.query_similarities(off, rows, ops.perm_table(ops.legacy_permutations(P, D, seed=42), DEV), b, K)
     torch.cuda.synchronize()
     assert ops.wide_ids(ops.id_bits_for(nq))
