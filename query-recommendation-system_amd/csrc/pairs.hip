@@ -745,6 +745,7 @@ __device__ static inline bool region_finish(const uint64_t *__restrict__ in, int
   __shared__ uint32_t seg[SEG];
   __shared__ uint32_t rowcnt[RG_ROWS], rowstart[RG_ROWS + 1], rowfill[RG_ROWS];
   __shared__ uint32_t sub[RG_ROWS], substart[RG_ROWS + 1], subfill[RG_ROWS];
+  __shared__ uint64_t longmask[RG_ROWS / WAVE];
   __shared__ uint32_t wsum[RG_ROWS / WAVE];
   __shared__ uint32_t full, ndist;
   const int t = threadIdx.x, lane = t & (WAVE - 1), wv = t >> 6;
@@ -810,6 +811,8 @@ __device__ static inline bool region_finish(const uint64_t *__restrict__ in, int
       if (k < wv) base += wsum[k];
     rowstart[t] = base + inc - c;
     if (t == RG_ROWS - 1) rowstart[RG_ROWS] = base + inc;
+    const uint64_t lm = __ballot(c > (uint32_t)RG_LONGROW);  // which of this wave's 64 rows are popular queries
+    if (lane == 0) longmask[wv] = lm;
   }
   __syncthreads();
   const uint32_t u = rowstart[RG_ROWS];
@@ -842,9 +845,10 @@ __device__ static inline bool region_finish(const uint64_t *__restrict__ in, int
   // hash table's space, which is dead by now) and then ranked inside their sub-bucket.
   const int sh = jbits > 8 ? jbits - 8 : 0;
   uint32_t *seg2 = tab;
-  for (int row = 0; row < RG_ROWS; ++row) {  // uniform: every thread sees the same rowstart[]
+  for (int part = 0; part < RG_ROWS / WAVE; ++part)
+  for (uint64_t lm = longmask[part]; lm; lm &= lm - 1) {  // uniform: every thread reads the same masks
+    const int row = part * WAVE + __ffsll((long long)lm) - 1;
     const uint32_t rs = rowstart[row], n = rowstart[row + 1] - rs;
-    if (n <= (uint32_t)RG_LONGROW) continue;
     __syncthreads();  // the previous long row (or the short-row loop) is done with sub* / seg2
     if (t < RG_ROWS) {
       sub[t] = 0;
@@ -1062,15 +1066,50 @@ __device__ static inline uint32_t rev_src(uint64_t w, int id_bits, bool wide) {
   return (uint32_t)(wide ? w >> 11 : w >> (id_bits + 11));
 }
 
-// start[q] = first position of `a` whose src is >= q (q = 0 .. nq); a is ordered by src.  FWD: a = pairs, src = i.
-template <bool FWD>
-__global__ __launch_bounds__(256) void edge_bounds_kernel(const uint64_t *__restrict__ a, int64_t n, int64_t nq,
-                                                          int id_bits, int wide, uint32_t *__restrict__ start) {
+// start[q] = first position of `a` whose src is >= q (q = 0 .. nq); a is ordered by src.  blockIdx.y = 0: a = the
+// pairs, src = i -> fstart; 1: a = the sorted reverse words, src = j -> rstart.  The thread at a change of src
+// fills the (usually 1 - 2) entries up to its src; a long stretch of queries without any edge (the ids beyond
+// the last i, below the first j, ...) is left at SEL_UNSET for edge_bounds_fix_kernel, whose threads find their
+// entry by binary search -- one thread walking a million-entry gap was the whole cost of this step.
+constexpr uint32_t SEL_UNSET = 0xFFFFFFFFu;  // n < 2^31: never a position
+constexpr int SEL_GAP = 32;
+__device__ static inline int64_t edge_src(const uint64_t *__restrict__ a, int64_t t, bool fwd, int id_bits, bool wide) {
+  return (int64_t)(fwd ? (uint32_t)(a[t] >> 32) : rev_src(a[t], id_bits, wide));
+}
+__global__ __launch_bounds__(256) void edge_bounds_kernel(const uint64_t *__restrict__ pairs,
+                                                          const uint64_t *__restrict__ rev, int64_t n, int64_t nq,
+                                                          int id_bits, int wide, uint32_t *__restrict__ fstart,
+                                                          uint32_t *__restrict__ rstart) {
+  const bool fwd = blockIdx.y == 0;
+  const uint64_t *a = fwd ? pairs : rev;
+  uint32_t *start = fwd ? fstart : rstart;
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t > n) return;
-  const int64_t s = t < n ? (int64_t)(FWD ? (uint32_t)(a[t] >> 32) : rev_src(a[t], id_bits, wide != 0)) : nq;
-  const int64_t p = t > 0 ? (int64_t)(FWD ? (uint32_t)(a[t - 1] >> 32) : rev_src(a[t - 1], id_bits, wide != 0)) : -1;
+  const int64_t s = t < n ? edge_src(a, t, fwd, id_bits, wide != 0) : nq;
+  const int64_t p = t > 0 ? edge_src(a, t - 1, fwd, id_bits, wide != 0) : -1;
+  if (s - p > SEL_GAP) {
+    if (s <= nq) start[s] = (uint32_t)t;  // the entry of s itself; the stretch below it stays unset
+    return;
+  }
   for (int64_t q = p + 1; q <= s && q <= nq; ++q) start[q] = (uint32_t)t;
+}
+
+__global__ __launch_bounds__(256) void edge_bounds_fix_kernel(const uint64_t *__restrict__ pairs,
+                                                              const uint64_t *__restrict__ rev, int64_t n, int64_t nq,
+                                                              int id_bits, int wide, uint32_t *__restrict__ fstart,
+                                                              uint32_t *__restrict__ rstart) {
+  const bool fwd = blockIdx.y == 0;
+  const uint64_t *a = fwd ? pairs : rev;
+  uint32_t *start = fwd ? fstart : rstart;
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q > nq || start[q] != SEL_UNSET) return;
+  int64_t lo = 0, hi = n;  // first position whose src is >= q
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (edge_src(a, mid, fwd, id_bits, wide != 0) >= q) hi = mid;
+    else lo = mid + 1;
+  }
+  start[q] = (uint32_t)lo;
 }
 
 constexpr int SEL_SHORT = 16;   // lists up to here: one 16-lane group per query (every query is visited)
@@ -1392,10 +1431,16 @@ QRLSH_EXPORT int qrlsh_topk_select_count(const uint64_t *pairs, int64_t n, const
     qrlsh_set_error("qrlsh_topk_select_count: hipMemsetAsync failed");
     return QRLSH_EHIP;
   }
-  const dim3 g1((unsigned)ceil_div64(n + 1, 256)), blk(256);
-  QR_LAUNCH("topk_bounds", (edge_bounds_kernel<true>), g1, blk, 0, st, pairs, n, nq, id_bits, 0, w.fstart);
-  QR_LAUNCH("topk_bounds", (edge_bounds_kernel<false>), g1, blk, 0, st, rev_sorted, n, nq, id_bits, rev_dst ? 1 : 0,
-            w.rstart);
+  const dim3 blk(256);
+  // both start arrays (contiguous in the workspace) to "unset", boundaries, then the long stretches
+  if (hipMemsetAsync(w.fstart, 0xFF, (size_t)((char *)w.medlist - (char *)w.fstart), st) != hipSuccess) {
+    qrlsh_set_error("qrlsh_topk_select_count: hipMemsetAsync failed");
+    return QRLSH_EHIP;
+  }
+  QR_LAUNCH("topk_bounds", edge_bounds_kernel, dim3((unsigned)ceil_div64(n + 1, 256), 2), blk, 0, st, pairs, rev_sorted, n,
+            nq, id_bits, rev_dst ? 1 : 0, w.fstart, w.rstart);
+  QR_LAUNCH("topk_bounds", edge_bounds_fix_kernel, dim3((unsigned)ceil_div64(nq + 1, 256), 2), blk, 0, st, pairs,
+            rev_sorted, n, nq, id_bits, rev_dst ? 1 : 0, w.fstart, w.rstart);
   QR_LAUNCH("topk_len", topk_len_kernel, dim3((unsigned)ceil_div64(nq + 1, LEN_QPB)), blk, 0, st, (const uint32_t *)w.fstart,
             (const uint32_t *)w.rstart, nq, K, w.off, w.medlist, w.longlist,
             reinterpret_cast<unsigned long long *>(w.nlong));

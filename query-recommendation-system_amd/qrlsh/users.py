@@ -47,28 +47,38 @@ def center_rows(ratings):
     return out
 
 
-def user_similarities(ratings, labels, K=None, device="cuda"):
-    """ratings (nu, nq) integers (0 = missing), labels (nu,) cluster ids ->
-    (src, dst, milli) int32 device tensors: for every user its at most K most similar users of the same cluster
-    with POSITIVE rounded similarity, sorted by (user, value descending, neighbour id ascending).
-    The reference's lists can also hold zero-valued entries (the user itself, negative cosines set to 0) when a
-    cluster has fewer than K positive neighbours; they weigh nothing in weighted_average and are left out."""
+def cluster_pair_scores(ratings, labels, device="cuda"):
+    """(pairs int64 [n] = u << 32 | v with u < v and labels[u] == labels[v], sorted; milli int32 [n] =
+    rint(1000 * cosine of the two truncated centred rows)) on the device -- the O(sum of cluster_size^2 * nq)
+    part of recommender.py:263-276, every entry of every cluster's similarity matrix above its diagonal"""
     r = ratings if isinstance(ratings, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(ratings), dtype=np.int32))
     r = r.to(device=device, dtype=torch.int32).contiguous()
     nu = r.shape[0]
-    if K is None:
-        K = max_candidates(nu)
     lab = labels if isinstance(labels, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(labels), dtype=np.int64))
     keys = lab.to(device=device, dtype=torch.int64).reshape(1, nu).contiguous()
     rows = center_rows(r)
     norms = ops.row_norms(rows)
     pairs = ops.candidate_pairs(keys, 4)                    # users sharing a label, u < v, sorted
-    z = torch.empty((0,), dtype=torch.int32, device=device)
     if pairs.numel() == 0:
-        return z, z.clone(), z.clone()
-    milli = ops.score_pairs(rows, norms, pairs)[0]
+        return pairs, torch.empty((0,), dtype=torch.int32, device=device)
+    return pairs, ops.score_pairs(rows, norms, pairs)[0]
+
+
+def user_similarities(ratings, labels, K=None, device="cuda"):
+    """ratings (nu, nq) integers (0 = missing), labels (nu,) cluster ids ->
+    (src, dst, milli) int32 device tensors: for every user its at most K most similar users of the same cluster
+    with POSITIVE rounded similarity, sorted by (user, value descending, neighbour id ascending).
+    The reference's lists can also hold zero-valued entries (the user itself, negative cosines set to 0) when a
+    cluster has fewer than K positive neighbours -- they weigh nothing in weighted_average and are left out --
+    and it orders equal values arbitrarily (np.argsort); when a tie straddles the K-th place the two cuts keep
+    different (equally similar) neighbours.  reference_cut() reproduces the reference's own order on the host."""
+    nu = ratings.shape[0]
+    if K is None:
+        K = max_candidates(nu)
+    pairs, milli = cluster_pair_scores(ratings, labels, device)
+    z = torch.empty((0,), dtype=torch.int32, device=device)
     keep = milli > 0                                         # :276 negatives -> 0; zero weights are dropped
-    pairs, milli = pairs[keep], milli[keep].contiguous()
+    pairs, milli = pairs[keep].contiguous(), milli[keep].contiguous()
     if pairs.numel() == 0:
         return z, z.clone(), z.clone()
     ib = ops.id_bits_for(nu)
@@ -78,7 +88,40 @@ def user_similarities(ratings, labels, K=None, device="cuda"):
         rev = ((pj << 11) | inv, pi.to(torch.int32))
     else:
         rev = (pj << (ib + 11)) | (inv << ib) | pi
-    return ops.topk_select(pairs.contiguous(), milli, rev, K, ib, nu)
+    return ops.topk_select(pairs, milli, rev, K, ib, nu)
+
+
+def reference_cut(pairs, milli, labels, K):
+    """The reference's own per-user cut (recommender.py:273-288) applied on the host to the device's scores:
+    per cluster the dense similarity matrix (milli / 1000, diagonal and negatives 0), per user
+    np.argsort(row)[::-1][:K] -- the same numpy call on the same values, hence the same (arbitrary) order among
+    ties and the same zero-valued entries as the reference.  -> {u: {'indexes', 'values'}}"""
+    labels = np.asarray(labels)
+    p = pairs.cpu().numpy()
+    m = milli.cpu().numpy()
+    pu, pv = (p >> 32).astype(np.int64), (p & 0xFFFFFFFF).astype(np.int64)
+    order = np.argsort(labels[pu], kind="stable")
+    pu, pv, m = pu[order], pv[order], m[order]
+    lab_of_pair = labels[pu]
+    cuts = np.flatnonzero(np.diff(lab_of_pair)) + 1
+    seg = dict(zip(lab_of_pair[np.concatenate(([0], cuts))].tolist() if len(pu) else [],
+                   zip(np.concatenate(([0], cuts)).tolist(), np.concatenate((cuts, [len(pu)])).tolist())))
+    out = {}
+    for c in np.unique(labels):
+        members = np.flatnonzero(labels == c)
+        local = {int(u): k for k, u in enumerate(members)}
+        sim = np.zeros((len(members), len(members)), dtype=np.float64)
+        if int(c) in seg:
+            a, b = seg[int(c)]
+            li = np.fromiter((local[int(u)] for u in pu[a:b]), dtype=np.int64, count=b - a)
+            lj = np.fromiter((local[int(v)] for v in pv[a:b]), dtype=np.int64, count=b - a)
+            val = np.maximum(m[a:b], 0).astype(np.float64) / 1000.0
+            sim[li, lj] = val
+            sim[lj, li] = val
+        for k, u in enumerate(members):
+            best = np.argsort(sim[k])[::-1][:K]
+            out[int(u)] = {"indexes": members[best], "values": sim[k][best]}
+    return out
 
 
 def sims_to_dict(src, dst, val, nu):

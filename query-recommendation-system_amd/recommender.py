@@ -167,9 +167,10 @@ class Recommender:
     def compute_userSimilarities(self):
         """{u: {'indexes', 'values'}} (recommender.py:216-290): StandardScaler -> PCA -> BIRCH (scikit-learn, as
         in the reference), then on the device the centred cosine inside each cluster (with the reference's
-        integer truncation of the centred rows) and the top round(log_1.5 nu) per user.  Entries of value 0
-        (the user itself, negative cosines) that the reference keeps when a cluster is small are left out: they
-        weigh nothing in weighted_average."""
+        integer truncation of the centred rows); the per-user cut is the reference's own numpy call
+        (np.argsort(row)[::-1][:K], :282) on those scores, so the lists -- tie order and zero-valued entries
+        included -- are the reference's.  qrlsh.users.user_similarities is the all-device variant with a
+        defined tie order (value descending, id ascending) for sizes where a host loop per user is not wanted."""
         from qrlsh import users
         t0 = time.time()
         nu = self.usersIDs.size
@@ -178,8 +179,8 @@ class Recommender:
         self._log("\nMax user candidates: {}, Total users: {}".format(top, nu))
         self._log("\nCluster count: {}, Total users: {}".format(n_clusters, nu))
         label = users.cluster_labels(self.ratings)
-        src, dst, val = users.user_similarities(self.ratings, label, top, self.device)
-        user_sim = users.sims_to_dict(src, dst, val, nu)
+        pairs, milli = users.cluster_pair_scores(self.ratings, label, self.device)
+        user_sim = users.reference_cut(pairs, milli, label, top)
         self._log("\n" + str(round(time.time() - t0, 3)) + "s for overall users_similarity scores")
         return user_sim
 

@@ -661,6 +661,21 @@ def test_sharded_driver_on_gpu_equals_single_gpu(tmp_path, world, mode, backend,
     _check_sharded_against(outs, res, nq, world)
 
 
+def test_sharded_config3_shape_four_ranks(tmp_path):
+    """BASELINE configs[3]'s workload (10 M queries x 128 / 32) through the sharded driver, four ranks sharing the
+    GPU (gloo, collectives staged through the host): two-step BIGID-free partition per owned band over all 10 M
+    queries, balanced pair hosting, row fetch, edge exchange, re-based top-K -- equal to the one-GPU result"""
+    nq, D, P, b, world = 10_000_000, 32768, 128, 32, 4
+    outs = _run_dist_gpu(tmp_path, world, nq, D, P, b, "all_to_all", "gloo", 29611, "fetch")
+    K = pipeline.max_candidates(nq)
+    off, rows = qrlsh.synth_csr(nq, D, seed=0, device=DEV)
+    res = pipeline.query_similarities(off, rows, ops.perm_table(ops.legacy_permutations(P, D, seed=42), DEV), b, K)
+    torch.cuda.synchronize()
+    _check_sharded_against(outs, res, nq, world)
+    sizes = [len(o["pairs"]) for o in outs]
+    assert max(sizes) < 1.05 * sum(sizes) / world                # the scoring work is split evenly
+
+
 def test_sharded_driver_wide_ids_beyond_2_pow_26(tmp_path):
     """config-5-sized id space through the SHARDED driver on the device: nq_total > 2^26 (key + payload
     edges, re-based to 64-bit local keys on arrival), more than 2^24 records per owned band (BIGID
@@ -1000,6 +1015,12 @@ def test_device_user_similarity_matches_reference(sub):
             for u in range(nu)}
     _check_user_sims_tie_aware(mine, gold, K)
     _check_user_sims_tie_aware(mine, O.user_similarities_from_labels(ratings, labels), K)
+    # the drop-in's form: the device's scores cut by the reference's own numpy call -> the reference's lists
+    # exactly, tie order and zero-valued entries included
+    pairs, milli = users.cluster_pair_scores(ratings, labels, DEV)
+    exact = users.reference_cut(pairs, milli, labels, K)
+    for u in range(nu):
+        assert np.array_equal(exact[u]["indexes"], gold[u]["indexes"]) and np.array_equal(exact[u]["values"], gold[u]["values"])
     # the centred rows themselves: truncation toward zero, zeros untouched
     c = users.center_rows(dev(ratings.astype(np.int32))).cpu().numpy()[:, :ratings.shape[1]]
     ref = ratings.astype(np.int64).copy()

@@ -40,7 +40,9 @@ LABELS = [
     (r"^part_scatter_atomic_kernel", "part_scatter"), (r"^row_unique_long_kernel", "row_unique_long"),
     (r"^region_unique_kernel", "region_unique"), (r"^region_gather_kernel", "region_gather"),
     (r"^region_bounds_kernel", "region_bounds"), (r"^region_unique_big_kernel", "region_unique_big"),
-    (r"^edge_bounds_kernel", "topk_bounds"), (r"^topk_len_kernel", "topk_len"), (r"^topk_select_kernel", "topk_select"),
+    (r"^edge_bounds_kernel", "topk_bounds"), (r"^edge_bounds_fix_kernel", "topk_bounds"), (r"^topk_len_kernel", "topk_len"),
+    (r"^topk_select_short_kernel", "topk_select"), (r"^topk_select_medium_kernel", "topk_select_medium"),
+    (r"^topk_select_long_kernel", "topk_select_long"), (r"^center_rows_kernel", "center_rows"),
     (r"^compact_count_kernel<0>", "unique_count"), (r"^compact_fill_kernel<0>", "unique_fill"),
     (r"^compact_count_kernel<1>", "topk_count"), (r"^compact_fill_kernel<1>", "topk_fill"),
     (r"^score_pairs_kernel", "score_pairs"), (r"^scan_u64_kernel", "scan_blocks"), (r"^synth_kernel", "synth"),
