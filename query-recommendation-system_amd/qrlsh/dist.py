@@ -50,20 +50,25 @@ class HipBackend:
     rows_hint = 0   # queries this rank owns (set by the driver): sizes the rows of the pair de-dup
     validate = True  # check the answer sets before MinHash gathers by their row ids (ops.check_csr)
 
+    def __init__(self):
+        self.stats = {}   # which paths the kernels took (bucket_path, dedup_path, group_bits, part_bits)
+
     def minhash(self, offsets, rows, table, b):
         return ops.minhash(offsets, rows, table, b=b, want_norm=True, compact=ops.can_compact(table),
                            validate=self.validate)
 
     def emit_pairs(self, keys, r):
-        return ops.emit_pairs_any(keys, r)
+        return ops.emit_pairs_any(keys, r, self.stats)
 
     def emit_pairs_chunked(self, recv, world, nb, nql, r):
         """emit_pairs on the [world][nb][nql] buffer of the band-partitioned exchange, read in place;
         the transposing copy to [nb][world * nql] is made only if the general path is needed"""
         pairs = ops.emit_pairs_fast(recv, r, chunks=(world, nb, nql))
         if pairs is not None:
+            self.stats["bucket_path"] = "partition+lds"
+            self.stats["part_bits"] = ops.part_bits_for(world * nql)
             return pairs
-        return ops.emit_pairs_any(_owned_bands(recv, world, nb, nql), r)
+        return ops.emit_pairs_any(_owned_bands(recv, world, nb, nql), r, self.stats)
 
     def group_pairs_by_host(self, pairs, nql, world):
         """pairs ordered by the rank that scores them -> (grouped, bounds int64 [world + 1] on the device)"""
@@ -74,7 +79,7 @@ class HipBackend:
 
     def sort_unique(self, words, nids):
         # the words a rank receives touch ~2 x its own share of the ids (the other endpoint of half its pairs)
-        return ops.unique_pairs(words, nids, words_per_query=words.numel() / max(1, 2 * (self.rows_hint or 1)))
+        return ops.unique_pairs(words, nids, self.stats, words_per_query=words.numel() / max(1, 2 * (self.rows_hint or 1)))
 
     def remote_ids(self, pairs, q0, nql, nids, world):
         return ops.remote_ids(pairs, q0, nql, nids, world)
@@ -394,5 +399,7 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
     ph.done("7_topk")
     stats["unique_pairs"] = int(pairs.numel())
     stats["kept_edges"] = int(src.numel())
+    stats["topk"] = "sort" if world > 1 else "sort-stable"
+    stats.update(getattr(be, "stats", {}))
     ph.close()
     return HotPathResult(sig[:n_real], norm2[:n_real], pairs, milli, src, dst, val, K, b, stats)
