@@ -15,6 +15,7 @@
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SCORE_LPP = 16;  // lanes per pair
 
@@ -51,8 +52,11 @@ __global__ __launch_bounds__(256) void score_pairs_kernel(const SigT *__restrict
     // row table in two pieces (sharded driver): rows below `split` are the rank's own, the rest were fetched
     const SigT *a = i < split ? sig + (size_t)i * P : sig_b + (size_t)(i - split) * P;
     const SigT *c = j < split ? sig + (size_t)j * P : sig_b + (size_t)(j - split) * P;
+    // norm2 == NULL: the two squared norms are summed from the rows themselves, which are in registers anyway -- a
+    // precomputed norm is one more random 64-B sector per row fetched (a quarter of a compact 256-B row on top)
+    const bool own_norms = norm2 == nullptr;
     int64_t na = 0, nb = 0;
-    if (live && lig == 0) {
+    if (!own_norms && live && lig == 0) {
       na = i < split ? norm2[i] : norm2_b[i - split];
       nb = j < split ? norm2[j] : norm2_b[j - split];
     }
@@ -63,21 +67,77 @@ __global__ __launch_bounds__(256) void score_pairs_kernel(const SigT *__restrict
           if (IS16) {
             const u16x8 x = *reinterpret_cast<const u16x8 *>(a + col);
             const u16x8 y = *reinterpret_cast<const u16x8 *>(c + col);
+            // no value of either chunk has bit 15 set (always so for D <= 32768 and non-empty answer sets; 0xFFFF,
+            // the -1 of an empty set, has it): four products then fit 32 bits and v_dot2_u32_u16 sums two element
+            // pairs per instruction on the packed words as loaded -- ~20 instructions per lane instead of ~45
+            // (unpack, -1 test, 64-bit multiply-add per element).  Decided per chunk from the data, same integers.
+            const u32x4 xw = __builtin_bit_cast(u32x4, x), yw = __builtin_bit_cast(u32x4, y);
+            const uint32_t hi = (xw[0] | xw[1] | xw[2] | xw[3] | yw[0] | yw[1] | yw[2] | yw[3]) & 0x80008000u;
+            if (hi == 0) {
+              uint32_t s0 = __builtin_amdgcn_udot2(__builtin_shufflevector(x, x, 0, 1),
+                                                   __builtin_shufflevector(y, y, 0, 1), 0u, false);
+              uint32_t s1 = __builtin_amdgcn_udot2(__builtin_shufflevector(x, x, 2, 3),
+                                                   __builtin_shufflevector(y, y, 2, 3), 0u, false);
+              s0 = __builtin_amdgcn_udot2(__builtin_shufflevector(x, x, 4, 5), __builtin_shufflevector(y, y, 4, 5),
+                                          s0, false);
+              s1 = __builtin_amdgcn_udot2(__builtin_shufflevector(x, x, 6, 7), __builtin_shufflevector(y, y, 6, 7),
+                                          s1, false);
+              dot += (int64_t)((uint64_t)s0 + (uint64_t)s1);
+              if (own_norms) {
+                uint32_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+                a0 = __builtin_amdgcn_udot2(__builtin_shufflevector(x, x, 0, 1), __builtin_shufflevector(x, x, 0, 1), a0, false);
+                a1 = __builtin_amdgcn_udot2(__builtin_shufflevector(x, x, 2, 3), __builtin_shufflevector(x, x, 2, 3), a1, false);
+                a0 = __builtin_amdgcn_udot2(__builtin_shufflevector(x, x, 4, 5), __builtin_shufflevector(x, x, 4, 5), a0, false);
+                a1 = __builtin_amdgcn_udot2(__builtin_shufflevector(x, x, 6, 7), __builtin_shufflevector(x, x, 6, 7), a1, false);
+                b0 = __builtin_amdgcn_udot2(__builtin_shufflevector(y, y, 0, 1), __builtin_shufflevector(y, y, 0, 1), b0, false);
+                b1 = __builtin_amdgcn_udot2(__builtin_shufflevector(y, y, 2, 3), __builtin_shufflevector(y, y, 2, 3), b1, false);
+                b0 = __builtin_amdgcn_udot2(__builtin_shufflevector(y, y, 4, 5), __builtin_shufflevector(y, y, 4, 5), b0, false);
+                b1 = __builtin_amdgcn_udot2(__builtin_shufflevector(y, y, 6, 7), __builtin_shufflevector(y, y, 6, 7), b1, false);
+                na += (int64_t)((uint64_t)a0 + (uint64_t)a1);
+                nb += (int64_t)((uint64_t)b0 + (uint64_t)b1);
+              }
+            } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) dot += c16(x[e]) * c16(y[e]);
+              for (int e = 0; e < 8; ++e) {
+                const int64_t xe = c16(x[e]), ye = c16(y[e]);
+                dot += xe * ye;
+                if (own_norms) {
+                  na += xe * xe;
+                  nb += ye * ye;
+                }
+              }
+            }
           } else {
             const i32x4 x = *reinterpret_cast<const i32x4 *>(a + col);
             const i32x4 y = *reinterpret_cast<const i32x4 *>(c + col);
             dot += (int64_t)x.x * y.x + (int64_t)x.y * y.y + (int64_t)x.z * y.z + (int64_t)x.w * y.w;
+            if (own_norms) {
+              na += (int64_t)x.x * x.x + (int64_t)x.y * x.y + (int64_t)x.z * x.z + (int64_t)x.w * x.w;
+              nb += (int64_t)y.x * y.x + (int64_t)y.y * y.y + (int64_t)y.z * y.z + (int64_t)y.w * y.w;
+            }
           }
         }
       } else {
-        for (int col = lig; col < P; col += SCORE_LPP)
-          dot += IS16 ? c16((unsigned short)a[col]) * c16((unsigned short)c[col]) : (int64_t)a[col] * (int64_t)c[col];
+        for (int col = lig; col < P; col += SCORE_LPP) {
+          const int64_t xe = IS16 ? c16((unsigned short)a[col]) : (int64_t)a[col];
+          const int64_t ye = IS16 ? c16((unsigned short)c[col]) : (int64_t)c[col];
+          dot += xe * ye;
+          if (own_norms) {
+            na += xe * xe;
+            nb += ye * ye;
+          }
+        }
       }
     }
 #pragma unroll
     for (int m = 1; m < SCORE_LPP; m <<= 1) dot += __shfl_xor(dot, m, WAVE);
+    if (own_norms) {  // uniform
+#pragma unroll
+      for (int m = 1; m < SCORE_LPP; m <<= 1) {
+        na += __shfl_xor(na, m, WAVE);
+        nb += __shfl_xor(nb, m, WAVE);
+      }
+    }
     if (live && lig == 0) {
       double cs = 0.0;
       if (na != 0 && nb != 0) cs = (double)dot / (sqrt((double)na) * sqrt((double)nb));
@@ -145,7 +205,7 @@ QRLSH_EXPORT int qrlsh_score_pairs(const void *sig, int32_t sig_dtype, const int
   QR_CHECK_ARG(n >= 0 && P > 0, "qrlsh_score_pairs: bad sizes n=%lld P=%d", (long long)n, P);
   QR_CHECK_ARG(sig_dtype == QRLSH_SIG_I32 || sig_dtype == QRLSH_SIG_U16, "qrlsh_score_pairs: bad sig_dtype %d", sig_dtype);
   if (n == 0) return QRLSH_OK;
-  QR_CHECK_ARG(sig && norm2 && pairs && milli_out, "qrlsh_score_pairs: null pointer");
+  QR_CHECK_ARG(sig && pairs && milli_out, "qrlsh_score_pairs: null pointer");
   if (edge_out && !edge_dst_out)
     QR_CHECK_ARG(id_bits > 0 && id_bits <= 26, "qrlsh_score_pairs: id_bits=%d must be in [1,26] without edge_dst_out", id_bits);
   QR_CHECK_ARG(!edge_dst_out || edge_out, "qrlsh_score_pairs: edge_dst_out needs edge_out");
@@ -162,7 +222,7 @@ QRLSH_EXPORT int qrlsh_score_pairs_rev(const void *sig, int32_t sig_dtype, const
   QR_CHECK_ARG(sig_dtype == QRLSH_SIG_I32 || sig_dtype == QRLSH_SIG_U16, "qrlsh_score_pairs_rev: bad sig_dtype %d",
                sig_dtype);
   if (n == 0) return QRLSH_OK;
-  QR_CHECK_ARG(sig && norm2 && pairs && milli_out && rev_out, "qrlsh_score_pairs_rev: null pointer");
+  QR_CHECK_ARG(sig && pairs && milli_out && rev_out, "qrlsh_score_pairs_rev: null pointer");
   QR_CHECK_ARG(rev_dst_out || (id_bits > 0 && id_bits <= 26),
                "qrlsh_score_pairs_rev: id_bits=%d must be in [1,26] without rev_dst_out", id_bits);
   return score_launch(sig, nullptr, 1ll << 32, sig_dtype, norm2, nullptr, P, pairs, n, milli_out, nullptr, rev_out, id_bits,
@@ -179,9 +239,10 @@ QRLSH_EXPORT int qrlsh_score_pairs_split(const void *sig, const int64_t *norm2, 
   QR_CHECK_ARG(sig_dtype == QRLSH_SIG_I32 || sig_dtype == QRLSH_SIG_U16, "qrlsh_score_pairs_split: bad sig_dtype %d",
                sig_dtype);
   if (n == 0) return QRLSH_OK;
-  QR_CHECK_ARG(pairs && milli_out && (split_rows == 0 || (sig && norm2)), "qrlsh_score_pairs_split: null pointer");
+  QR_CHECK_ARG(pairs && milli_out && (split_rows == 0 || sig) && ((norm2 == nullptr) == (norm2_b == nullptr) || !sig_b),
+               "qrlsh_score_pairs_split: null pointer (norm2 and norm2_b: both or neither)");
   return score_launch(sig, sig_b, split_rows, sig_dtype, norm2, norm2_b, P, pairs, n, milli_out, nullptr, nullptr, 0,
-                      nullptr, stream);
+                      nullptr, stream, 0);
 }
 
 // Exact candidate test for wide bands (r > 4, hashed bucket ids): flags[t] = 1 iff the pair

@@ -96,7 +96,7 @@ class HipBackend:
     def score(self, sig, norm2, sig_b, norm2_b, pairs):
         """milli of pairs whose halves index the row table [sig | sig_b]"""
         if sig_b is None:
-            return ops.score_pairs(sig, norm2, pairs)[0]
+            sig_b, norm2_b = sig[:0], norm2[:0]
         return ops.score_pairs_split(sig, norm2, sig_b, norm2_b, pairs)
 
     def verify_flags(self, sig_rows, b, pairs):

@@ -543,7 +543,8 @@ def score_pairs(sig, norm2, pairs, want_cos=False, edge_id_bits=None, wide=None)
     if not isinstance(sig, torch.Tensor) or sig.dtype not in (torch.int32, torch.int16):
         raise TypeError("sig must be an int32 or int16 (compact) tensor")
     _need(sig, sig.dtype, "sig", 2)
-    _need(norm2, torch.int64, "norm2", 1)
+    if norm2 is not None:       # None: the kernel sums the norms from the rows itself (exact too, but slower)
+        _need(norm2, torch.int64, "norm2", 1)
     _need(pairs, torch.int64, "pairs", 1)
     n = pairs.numel()
     dev = sig.device
@@ -672,7 +673,8 @@ def score_pairs_rev(sig, norm2, pairs, id_bits, wide=None):
     int64 [n] words, or with wide ids the tuple (keys int64 [n], dst int32 [n]).  Input of topk_select."""
     lib = _lib.load()
     _need(sig, sig.dtype, "sig", 2)
-    _need(norm2, torch.int64, "norm2", 1)
+    if norm2 is not None:
+        _need(norm2, torch.int64, "norm2", 1)
     _need(pairs, torch.int64, "pairs", 1)
     n, dev = pairs.numel(), sig.device
     if wide is None:

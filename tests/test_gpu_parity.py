@@ -359,6 +359,21 @@ def test_score_non_multiple_of_4_and_zero_rows():
     milli, _, _ = ops.score_pairs(d, ops.row_norms(d), dev(pairs.view(np.int64)))
     assert np.array_equal(milli.cpu().numpy(), O.score_pairs(sig, pairs, mode=1))
     assert np.array_equal(milli.cpu().numpy(), O.score_pairs(sig, pairs, mode=0))
+    # norms summed inside the kernel (norm2 = None) == precomputed norms: int32 rows (odd and vector widths) and
+    # compact uint16 rows with -1 entries
+    for P in (15, 16, 128):
+        s32 = rng.integers(-1, 30000, size=(50, P)).astype(np.int32)
+        s32[3] = -1
+        s32[9] = 0
+        ds = dev(s32)
+        ref = O.score_pairs(s32, pairs, mode=1)
+        assert np.array_equal(ops.score_pairs(ds, None, dev(pairs.view(np.int64)))[0].cpu().numpy(), ref)
+        assert np.array_equal(ops.score_pairs(ds, ops.row_norms(ds), dev(pairs.view(np.int64)))[0].cpu().numpy(), ref)
+        if P % 8 == 0:
+            d16 = dev(np.where(s32 < 0, 0xFFFF, s32).astype(np.uint16).view(np.int16))
+            assert np.array_equal(ops.score_pairs(d16, None, dev(pairs.view(np.int64)))[0].cpu().numpy(), ref)
+            m2, rev = ops.score_pairs_rev(d16, None, dev(pairs.view(np.int64)), 6)
+            assert np.array_equal(m2.cpu().numpy(), ref)
 
 
 @pytest.mark.parametrize("name", FULL)
@@ -437,7 +452,8 @@ def test_synth_generator_matches_oracle_twin():
 
 
 @pytest.mark.parametrize("nq,D,P,b", [(20000, 32768, 128, 32), (30000, 100000, 128, 32), (12000, 32768, 256, 64),
-                                      (200000, 32768, 128, 32), (25000, 32768, 100, 20), (9000, 70000, 96, 12)])
+                                      (200000, 32768, 128, 32), (25000, 32768, 100, 20), (9000, 70000, 96, 12),
+                                      (30000, 50000, 128, 32)])   # compact rows whose values pass 2^15: no dot2 form
 def test_pipeline_equals_oracle_on_synthetic(nq, D, P, b):
     K = pipeline.max_candidates(nq)
     off, rows = qrlsh.synth_csr(nq, D, seed=0, device=DEV)
