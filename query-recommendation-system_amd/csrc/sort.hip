@@ -524,81 +524,70 @@ __global__ __launch_bounds__(SORT_THREADS, 3) void part_scatter_staged_kernel(
 // LEVEL2 = false: the input is the band-major key matrix ([batch][n], ids = positions), 256 parts per band.
 // LEVEL2 = true : finer partitions (T > 8 bits) take a second step -- the input is the OUTPUT of a first
 // step, one batch per (band, coarse part): its in_counts[batch] records sit at batch * in_cap and are
-// dealt to nd = 2^(T-8) fine parts by the next bits of the same hash; ids come with the records.
-// BIGID = false: ids < 2^24, the part number rides in the top byte of the staged id; true (more than 2^24
-// queries): the staged id keeps all 32 bits and the part number is recomputed from (key, id) at write-out.
-template <bool LEVEL2, bool BIGID>
-__global__ __launch_bounds__(SORT_THREADS, 3) void part_scatter_atomic_kernel(
+// dealt to nd = 2^(T-c1) fine parts by the next bits of the same hash; ids come with the records.
+constexpr int PS_IPT = 16;  // records per thread of the atomic partition (8, six workgroups per CU: 3.9 ms against 3.4)
+constexpr int PS_TILE = SORT_THREADS * PS_IPT;
+constexpr int PS_WGS = 3;   // workgroups per CU the 50 KB LDS image allows
+template <bool LEVEL2>
+__global__ __launch_bounds__(SORT_THREADS, PS_WGS) void part_scatter_atomic_kernel(
     const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint64_t *__restrict__ keys_out,
     uint32_t *__restrict__ vals_out, int64_t n_in, int ntiles, int shift, uint32_t dmask,
     uint32_t *__restrict__ cursors, uint32_t cap, uint32_t *__restrict__ overflow, uint64_t ek,
     const uint32_t *__restrict__ in_counts, uint32_t in_cap, int64_t chunk_len, int64_t chunk_stride,
     int64_t band_stride) {
-  __shared__ uint32_t cnt[SORT_THREADS / WAVE][RADIX];
+  // What travels through the partition is x = mix64(key), not the key: mix64 is a bijection, so equal x <=> equal
+  // keys and the finish can pair on x; the part number of either step is then a shift of the staged word (no
+  // second hash in the second step, none at the write-out, nothing to carry in the id word -- ids keep all 32
+  // bits for any number of queries).  Records of empty bands (key == ek) never pair (lsh.py:47) and are dropped
+  // here; mix64(ek), which no other key maps to, is the finish's free-slot marker.
+  // The order of the records inside a part is free, so a record's place in its tile's share of a part is the old
+  // value of an LDS counter (one returning ds_add per record), not the eight ballots + popcount a stable rank
+  // costs: the kernel was VALU-bound on those (2200 vector instructions per wave, 66 % VALU-busy).
+  __shared__ uint32_t cnt[RADIX];
   __shared__ uint32_t lsum[SORT_THREADS / WAVE];
   __shared__ uint32_t gdelta[RADIX];
   __shared__ uint8_t gok[RADIX];
-  __shared__ uint64_t skey[SORT_TILE];
-  __shared__ uint32_t sval[SORT_TILE];
+  __shared__ uint64_t skey[PS_TILE];
+  __shared__ uint32_t sval[PS_TILE];
   const int tile = LEVEL2 ? (int)blockIdx.x : xcd_tile(blockIdx.x, ntiles), batch = blockIdx.y;
   const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x >> 6;
   const int64_t n = LEVEL2 ? (int64_t)min(in_counts[batch], in_cap) : n_in;
-  const int64_t tbase = (int64_t)tile * SORT_TILE;
+  const int64_t tbase = (int64_t)tile * PS_TILE;
   if (tbase >= n) return;  // LEVEL2: the grid covers a full region, this one holds fewer records (uniform)
-#pragma unroll
-  for (int i = 0; i < SORT_THREADS / WAVE; ++i) cnt[i][threadIdx.x] = 0;
+  cnt[threadIdx.x] = 0;
   __syncthreads();
   // first step: band `batch` of the key matrix, either plain ([b][n]: band_stride = n) or in chunks of
   // chunk_len queries chunk_stride words apart (what a band-partitioned all-to-all delivers: [rank][band][nql])
   const size_t boff = LEVEL2 ? (size_t)batch * in_cap : (size_t)batch * (size_t)(band_stride ? band_stride : n);
   const bool chunked = !LEVEL2 && chunk_len > 0 && chunk_len < n;
-  const int64_t wbase = tbase + (int64_t)w * (WAVE * SORT_IPT);
+  const int64_t wbase = tbase + (int64_t)w * (WAVE * PS_IPT);
   const uint32_t nd = dmask + 1u;  // parts per batch
-  uint64_t key[SORT_IPT];
-  uint32_t val[SORT_IPT];
-  uint32_t dr[SORT_IPT];
-  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  uint64_t key[PS_IPT];
+  uint32_t val[PS_IPT];
+  uint32_t dr[PS_IPT];  // part << 16 | place among the tile's records of that part; 0xFFFFFFFF = no record
 #pragma unroll
-  for (int k = 0; k < SORT_IPT; ++k) {
+  for (int k = 0; k < PS_IPT; ++k) {
     const int64_t idx = wbase + (int64_t)k * WAVE + lane;
     const size_t at = chunked ? boff + (size_t)(idx / chunk_len) * chunk_stride + (size_t)(idx % chunk_len) : boff + idx;
-    key[k] = idx < n ? keys_in[at] : 0;
+    key[k] = idx < n ? keys_in[at] : ek;
     val[k] = LEVEL2 ? (idx < n ? vals_in[boff + idx] : 0u) : (uint32_t)idx;
   }
 #pragma unroll
-  for (int k = 0; k < SORT_IPT; ++k) {
+  for (int k = 0; k < PS_IPT; ++k) {
     const int64_t idx = wbase + (int64_t)k * WAVE + lane;
-    const bool valid = idx < n;
-    const uint32_t d = part_digit<true>(key[k], (int64_t)val[k], shift, ek, dmask);
-    uint64_t m = __ballot(valid);
-#pragma unroll
-    for (int bit = 0; bit < 8; ++bit) {
-      const bool one = (d >> bit) & 1u;
-      const uint64_t bal = __ballot(one);
-      m &= one ? bal : ~bal;
-    }
-    const uint32_t below = (uint32_t)__popcll(m & lt_mask);
-    uint32_t prev = 0;
-    if (valid) {
-      prev = cnt[w][d];
-      if (below == 0) cnt[w][d] = prev + (uint32_t)__popcll(m);
-    }
-    dr[k] = (d << 16) | (prev + below);
+    const bool valid = idx < n && (LEVEL2 || key[k] != ek);
+    if (!LEVEL2) key[k] = qr_mix64(key[k]);
+    const uint32_t d = (uint32_t)(key[k] >> shift) & dmask;
+    dr[k] = valid ? (d << 16) | atomicAdd(&cnt[d], 1u) : 0xFFFFFFFFu;
   }
   __syncthreads();
   // thread d speaks for part d.  The reservation goes out first and its result is not touched until the
   // tile has been laid out in LDS (which needs local positions only): the atomic's round trip to memory
-  // runs beside the scan, the chaining and the staging.
-  uint32_t tc = 0;
-  {
-    const int d = threadIdx.x;
-#pragma unroll
-    for (int i = 0; i < SORT_THREADS / WAVE; ++i) tc += cnt[i][d];
-  }
+  // runs beside the scan and the staging.
+  const uint32_t tc = cnt[threadIdx.x];
   const uint32_t gb = tc ? atomicAdd(&cursors[(size_t)batch * nd + threadIdx.x], tc) : 0u;
   uint32_t lstart;
   {
-    const int d = threadIdx.x;
     uint32_t linc = tc;
 #pragma unroll
     for (int k = 1; k < WAVE; k <<= 1) {
@@ -611,22 +600,15 @@ __global__ __launch_bounds__(SORT_THREADS, 3) void part_scatter_atomic_kernel(
 #pragma unroll
     for (int k = 0; k < SORT_THREADS / WAVE; ++k)
       if (k < w) lstart += lsum[k];
-    uint32_t run = lstart;
-#pragma unroll
-    for (int i = 0; i < SORT_THREADS / WAVE; ++i) {
-      const uint32_t c = cnt[i][d];
-      cnt[i][d] = run;
-      run += c;
-    }
+    cnt[threadIdx.x] = lstart;
   }
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < SORT_IPT; ++k) {
-    const int64_t idx = wbase + (int64_t)k * WAVE + lane;
-    if (idx < n) {
-      const uint32_t d = dr[k] >> 16, lp = cnt[w][d] + (dr[k] & 0xFFFFu);
+  for (int k = 0; k < PS_IPT; ++k) {
+    if (dr[k] != 0xFFFFFFFFu) {
+      const uint32_t lp = cnt[dr[k] >> 16] + (dr[k] & 0xFFFFu);
       skey[lp] = key[k];
-      sval[lp] = BIGID ? val[k] : (val[k] | d << 24);
+      sval[lp] = val[k];
     }
   }
   {
@@ -637,19 +619,20 @@ __global__ __launch_bounds__(SORT_THREADS, 3) void part_scatter_atomic_kernel(
     gdelta[d] = (uint32_t)d * cap + gb - lstart;  // mod 2^32; + the staged position gives the place in the batch
   }
   __syncthreads();
-  const int ntile = (int)min((int64_t)SORT_TILE, n - tbase);
+  uint32_t nstaged = 0;  // records of the tile that are not of an empty band
+#pragma unroll
+  for (int k = 0; k < SORT_THREADS / WAVE; ++k) nstaged += lsum[k];
   const size_t obase = (size_t)batch * nd * cap;
 #pragma unroll
-  for (int k = 0; k < SORT_IPT; ++k) {
-    const int p = k * SORT_THREADS + threadIdx.x;
-    if (p < ntile) {
-      const uint32_t vv = sval[p];
-      const uint64_t kk = skey[p];
-      const uint32_t d = BIGID ? part_digit<true>(kk, (int64_t)vv, shift, ek, dmask) : vv >> 24;
+  for (int k = 0; k < PS_IPT; ++k) {
+    const uint32_t p = k * SORT_THREADS + threadIdx.x;
+    if (p < nstaged) {
+      const uint64_t x = skey[p];
+      const uint32_t d = (uint32_t)(x >> shift) & dmask;
       if (gok[d]) {
-        const size_t dst = obase + (uint32_t)(gdelta[d] + (uint32_t)p);
-        keys_out[dst] = kk;
-        vals_out[dst] = BIGID ? vv : (vv & 0xFFFFFFu);
+        const size_t dst = obase + (uint32_t)(gdelta[d] + p);
+        keys_out[dst] = x;
+        vals_out[dst] = sval[p];
       }
     }
   }
@@ -1123,12 +1106,15 @@ static uint32_t part_region(int64_t nq) {
   return (uint32_t)(c < FIN_CAP ? c : FIN_CAP);
 }
 
-// finer partitions (T > 8) go through two such kernels: 256 coarse regions per band, then 2^(T-8) fine
+// finer partitions (T > 8) go through two such kernels: 2^c1 coarse regions per band, then 2^(T-c1) fine
 // regions inside each (2 x mean + 128, at most the LDS image)
-static uint32_t coarse_region(int64_t nq) {
+// the T bits of a fine partition are split evenly over the two steps (6 + 6 at T = 12: runs of 64 records per
+// (tile, part) in both, 64 reservations per tile; 8 + 4 measured 3.71 ms against 3.45 at 10 M queries)
+static int coarse_bits(int T) { return (T + 1) / 2; }
+static uint32_t coarse_region(int64_t nq, int c1) {
   // equal keys share a region: beside the hash-uniform spread there must be room for popular keys (one
   // with more copies than the LDS image overflows the fine step anyway)
-  const double a = (double)nq / RADIX;
+  const double a = (double)nq / (double)(1 << c1);
   const double slack = a >= 4096.0 ? 0.25 * a + 8192.0 : 6.0 * sqrt(a) + 2.0 * a + 64.0;
   return (uint32_t)(((int64_t)(a + slack) + 63) / 64 * 64);
 }
@@ -1154,7 +1140,8 @@ QRLSH_EXPORT size_t qrlsh_bucket_tmp_words(int64_t nq, int32_t b, int32_t part_b
   if (nq <= 0 || b <= 0 || part_bits <= 8) return 0;
   const size_t plain = (size_t)b * nq;
   if (!one_kernel_partition(nq, part_bits)) return plain;
-  const size_t regions = (size_t)b * RADIX * coarse_region(nq);
+  const int c1 = coarse_bits(part_bits);
+  const size_t regions = ((size_t)b << c1) * coarse_region(nq, c1);
   return regions > plain ? regions : plain;
 }
 
@@ -1190,12 +1177,9 @@ QRLSH_EXPORT int qrlsh_bucket_pairs_emit_chunked(const uint64_t *keys, int64_t k
                (unsigned long long)capacity);
   const int nparts = 1 << part_bits;
   const BucketWs w = bucket_ws(workspace, nq, b, part_bits);
-  const bool bigid = nq > (1ll << 24);
-#define QR_PART_SCATTER(LEVEL2_, ...)                                                                          \
-  do {                                                                                                         \
-    if (bigid) QR_LAUNCH("part_scatter", (part_scatter_atomic_kernel<LEVEL2_, true>), __VA_ARGS__);            \
-    else QR_LAUNCH("part_scatter", (part_scatter_atomic_kernel<LEVEL2_, false>), __VA_ARGS__);                 \
-  } while (0)
+  // the atomic partition hands the finish x = mix64(key): its free-slot marker is mix64(empty key)
+  const uint64_t ekx = qr_mix64(qr_empty_key(r));
+#define QR_PART_SCATTER(LEVEL2_, ...) QR_LAUNCH("part_scatter", (part_scatter_atomic_kernel<LEVEL2_>), __VA_ARGS__)
   if (part_bits == 8 && one_kernel_partition(nq, part_bits)) {
     // one-kernel partition into fixed regions; the part cursors live where the general path keeps `starts`
     const uint32_t cap = part_region(nq);
@@ -1204,41 +1188,42 @@ QRLSH_EXPORT int qrlsh_bucket_pairs_emit_chunked(const uint64_t *keys, int64_t k
       qrlsh_set_error("qrlsh_bucket_pairs_emit: hipMemsetAsync failed");
       return QRLSH_EHIP;
     }
-    const int ntiles = (int)ceil_div64(nq, SORT_TILE);
+    const int ntiles = (int)ceil_div64(nq, PS_TILE);
     QR_PART_SCATTER(false, dim3(ntiles, b), dim3(SORT_THREADS), 0, st, keys, (const uint32_t *)nullptr, part_keys,
                     part_ids, nq, ntiles, 56, (uint32_t)RADIX - 1u, cursors, cap,
                     reinterpret_cast<uint32_t *>(total_overflow_out + 1), qr_empty_key(r), (const uint32_t *)nullptr, 0u,
                     key_chunk, key_chunk_stride, key_band_stride);
     QR_LAUNCH("bucket_emit", (bucket_finish_kernel<FIN_EMIT>), dim3(nparts, b), dim3(FIN_THREADS), 0, st,
               (const uint64_t *)part_keys, (const uint32_t *)part_ids, nq, (const uint32_t *)nullptr, nparts,
-              qr_empty_key(r), total_overflow_out, reinterpret_cast<uint32_t *>(total_overflow_out + 1), pairs_out,
+              ekx, total_overflow_out, reinterpret_cast<uint32_t *>(total_overflow_out + 1), pairs_out,
               capacity, (const uint32_t *)cursors, cap);
     QR_LAUNCH_CHECK("qrlsh_bucket_pairs_emit");
     return QRLSH_OK;
   }
   if (one_kernel_partition(nq, part_bits)) {
-    // two steps of the same kernel: 256 coarse regions per band into the tmp buffers, then every coarse
-    // region into its 2^(T-8) fine regions; cursors of step 1 borrow the histogram area, step 2's `starts`
+    // two steps of the same kernel: 2^c1 coarse regions per band into the tmp buffers, then every coarse
+    // region into its 2^(T-c1) fine regions; cursors of step 1 borrow the histogram area, step 2's `starts`
     const int T = part_bits;
-    const uint32_t cap1 = coarse_region(nq), cap2 = fine_region(nq, T), lowmask = (1u << (T - 8)) - 1u;
+    const int c1 = coarse_bits(T);
+    const uint32_t cap1 = coarse_region(nq, c1), cap2 = fine_region(nq, T), lowmask = (1u << (T - c1)) - 1u;
     uint32_t *cur1 = w.ghist, *cur2 = w.starts;
-    if (hipMemsetAsync(cur1, 0, (size_t)b * RADIX * sizeof(uint32_t), st) != hipSuccess ||
+    if (hipMemsetAsync(cur1, 0, ((size_t)b << c1) * sizeof(uint32_t), st) != hipSuccess ||
         hipMemsetAsync(cur2, 0, ((size_t)b << T) * sizeof(uint32_t), st) != hipSuccess) {
       qrlsh_set_error("qrlsh_bucket_pairs_emit: hipMemsetAsync failed");
       return QRLSH_EHIP;
     }
     uint32_t *ovf = reinterpret_cast<uint32_t *>(total_overflow_out + 1);
-    const int ntiles = (int)ceil_div64(nq, SORT_TILE);
+    const int ntiles = (int)ceil_div64(nq, PS_TILE);
     QR_PART_SCATTER(false, dim3(ntiles, b), dim3(SORT_THREADS), 0, st, keys, (const uint32_t *)nullptr, tmp_keys,
-                    tmp_ids, nq, ntiles, 56, (uint32_t)RADIX - 1u, cur1, cap1, ovf, qr_empty_key(r),
+                    tmp_ids, nq, ntiles, 64 - c1, (1u << c1) - 1u, cur1, cap1, ovf, qr_empty_key(r),
                     (const uint32_t *)nullptr, 0u, key_chunk, key_chunk_stride, key_band_stride);
-    QR_PART_SCATTER(true, dim3((unsigned)ceil_div64(cap1, SORT_TILE), b * RADIX), dim3(SORT_THREADS), 0, st,
+    QR_PART_SCATTER(true, dim3((unsigned)ceil_div64(cap1, PS_TILE), b << c1), dim3(SORT_THREADS), 0, st,
                     (const uint64_t *)tmp_keys, (const uint32_t *)tmp_ids, part_keys, part_ids, (int64_t)0, 0, 64 - T,
                     lowmask, cur2, cap2, ovf, qr_empty_key(r), (const uint32_t *)cur1, cap1, (int64_t)0, (int64_t)0,
                     (int64_t)0);
     QR_LAUNCH("bucket_emit", (bucket_finish_kernel<FIN_EMIT>), dim3(nparts, b), dim3(FIN_THREADS), 0, st,
               (const uint64_t *)part_keys, (const uint32_t *)part_ids, nq, (const uint32_t *)nullptr, nparts,
-              qr_empty_key(r), total_overflow_out, ovf, pairs_out, capacity, (const uint32_t *)cur2, cap2);
+              ekx, total_overflow_out, ovf, pairs_out, capacity, (const uint32_t *)cur2, cap2);
     QR_LAUNCH_CHECK("qrlsh_bucket_pairs_emit");
     return QRLSH_OK;
   }
