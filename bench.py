@@ -152,7 +152,8 @@ def load_traffic(nq_total, P, b):
             continue
         wl = j.get("workload", {})
         if (wl.get("nq_total"), wl.get("P"), wl.get("b")) != (nq_total, P, b):
-            why = "profiles/ holds no PMC pass of this workload"
+            if why.startswith("no profiles"):
+                why = "profiles/ holds no PMC pass of this workload"
             continue
         if j.get("csrc_sha") != fp:
             why = "the PMC pass in profiles/%s was taken on other kernel sources (%s != %s)" % (

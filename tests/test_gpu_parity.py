@@ -565,9 +565,9 @@ def test_full_size_256_perm_64_bands_equals_oracle():
 
 
 def test_more_than_2_pow_24_queries_equals_oracle():
-    """nq > 2^24 (the per-rank record count of configs 4-5): ids no longer fit the 24 bits the partition
-    kernel packs beside the part number (BIGID variant of part_scatter_atomic_kernel), T = 12; tiny P / b
-    keep it cheap.  Also drives the count-then-fill API, whose sort-based partition takes its non-staged
+    """nq > 2^24 (the per-rank record count of configs 4-5): ids need more than 24 bits of the partition's id
+    word (which carries nothing else: the partition stores mix64(key) and takes every part number from it),
+    T = 12; tiny P / b keep it cheap.  Also drives the count-then-fill API, whose sort-based partition takes its non-staged
     scatter for nq > 2^24 (sort.hip: bucket_partition), and the plain-layout size rules."""
     nq, D, P, b = 17_000_000, 32768, 8, 2
     assert nq > (1 << 24)
@@ -679,7 +679,7 @@ def test_sharded_driver_on_gpu_equals_single_gpu(tmp_path, world, mode, backend,
 
 def test_sharded_config3_shape_four_ranks(tmp_path):
     """BASELINE configs[3]'s workload (10 M queries x 128 / 32) through the sharded driver, four ranks sharing the
-    GPU (gloo, collectives staged through the host): two-step BIGID-free partition per owned band over all 10 M
+    GPU (gloo, collectives staged through the host): two-step partition per owned band over all 10 M
     queries, balanced pair hosting, row fetch, edge exchange, re-based top-K -- equal to the one-GPU result"""
     nq, D, P, b, world = 10_000_000, 32768, 128, 32, 4
     outs = _run_dist_gpu(tmp_path, world, nq, D, P, b, "all_to_all", "gloo", 29611, "fetch")
@@ -694,8 +694,8 @@ def test_sharded_config3_shape_four_ranks(tmp_path):
 
 def test_sharded_driver_wide_ids_beyond_2_pow_26(tmp_path):
     """config-5-sized id space through the SHARDED driver on the device: nq_total > 2^26 (key + payload
-    edges, re-based to 64-bit local keys on arrival), more than 2^24 records per owned band (BIGID
-    partition reading the exchanged key layout in place), two gloo ranks sharing the GPU."""
+    edges, re-based to 64-bit local keys on arrival), more than 2^24 records per owned band (32-bit ids
+    through the partition, which reads the exchanged key layout in place), two gloo ranks sharing the GPU."""
     nq, D, P, b, world = 68_000_000, 32768, 8, 2, 2       # r = 4: buckets stay small (r = 2 keys collide in the thousands)
     outs = _run_dist_gpu(tmp_path, world, nq, D, P, b, "all_to_all", "gloo", 29597, "fetch")
     K = pipeline.max_candidates(nq)
