@@ -31,6 +31,8 @@ def _run(tmp_path, world, nq, D, P, b, mode, port, extra=()):
                                                   (3, "all_to_all", 8, ("sig=all_gather",), 601),   # 601 = 3 * 201 - 2:
                                                   (3, "all_to_all", 8, ("sig=fetch",), 601),        # padded last shard
                                                   (4, "all_gather", 8, ("sig=fetch",), 598),
+                                                  (8, "all_to_all", 8, ("sig=fetch",), 603),        # the driver's N = 8:
+                                                  (8, "all_to_all", 32, ("sig=fetch",), 1001),      # one band / four bands per rank
                                                   (2, "all_to_all", 4, ("wide", "sig=fetch"), 600),
                                                   (2, "all_to_all", 4, ("wide", "sig=all_gather"), 599)])
 def test_sharded_equals_single_process(tmp_path, world, mode, b, extra, nq):
