@@ -36,10 +36,20 @@ def main():
     mean = float(sys.argv[9]) if len(sys.argv) > 9 else 16.0
     if mean != 16.0:
         off, rows = qrlsh.synth_csr(nq, D, seed=0, mean=mean, q0=q0, nq_local=n_real, device=dev)
+    if os.environ.get("QRLSH_TEST_TINY_EMIT_HINT"):
+        class _Tiny(dict):          # every shape looks "seen before, 16 pairs": the one-pass emit must count, then retry
+            def __contains__(self, key):
+                return True
+
+            def __missing__(self, key):
+                return 16
+        ops._EMIT_HINT = _Tiny()
     phases = {}
     res = qdist.query_similarities_sharded(off, rows, table, b, K, nq, exchange=mode, sig_exchange=sig_mode,
                                            phases=phases)
     assert phases["_steps"] == 1 and any(k.startswith("ms:") for k in phases)
+    if os.environ.get("QRLSH_TEST_TINY_EMIT_HINT") and res.stats["emitted_pairs"] > 0:
+        assert all(v > 16 for v in dict.values(ops._EMIT_HINT)) and len(ops._EMIT_HINT) > 0   # the retry recorded the real count
     torch.cuda.synchronize()
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), pairs=res.pairs.cpu().numpy(), milli=res.milli.cpu().numpy(),
              src=res.src.cpu().numpy(), dst=res.dst.cpu().numpy(), val=res.val.cpu().numpy(),

@@ -621,7 +621,7 @@ def test_wide_ids_beyond_2_pow_26_queries():
 
 
 # ---------------------------------------------------------------------------- sharded driver
-def _run_dist_gpu(tmp_path, world, nq, D, P, b, mode, backend, port, sig_mode="auto", mean=16.0):
+def _run_dist_gpu(tmp_path, world, nq, D, P, b, mode, backend, port, sig_mode="auto", mean=16.0, env_extra=None):
     import subprocess
     import sys as _sys
     torch.cuda.synchronize()
@@ -630,6 +630,7 @@ def _run_dist_gpu(tmp_path, world, nq, D, P, b, mode, backend, port, sig_mode="a
     env = dict(os.environ)
     env["OMP_NUM_THREADS"] = "1"
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    env.update(env_extra or {})
     cmd = [_sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "tests", "dist_gpu_worker.py"),
            str(tmp_path), str(nq), str(D), str(P), str(b), mode, backend, sig_mode, str(mean)]
@@ -670,6 +671,20 @@ def test_sharded_driver_on_gpu_equals_single_gpu(tmp_path, world, mode, backend,
             assert str(o["sig_exchange"]) == sig_mode
         if world > 1 and str(o["sig_exchange"]) == "fetch":
             assert 0 <= int(o["fetched"]) <= (world - 1) * nql   # only rows of the other shards, each once
+    K = pipeline.max_candidates(nq)
+    off, rows = qrlsh.synth_csr(nq, D, seed=0, device=DEV)
+    res = pipeline.query_similarities(off, rows, ops.perm_table(ops.legacy_permutations(P, D, seed=42), DEV), b, K)
+    torch.cuda.synchronize()
+    _check_sharded_against(outs, res, nq, world)
+
+
+def test_sharded_driver_retries_a_too_small_pair_buffer(tmp_path):
+    """the one-pass emit sizes its output from what the last call of the shape produced (ops._EMIT_HINT); a
+    guess that is far too small (here: 16 pairs, on every rank) must cost a second, exactly sized run and
+    nothing else -- same pairs, scores and top-K as the one-GPU pipeline"""
+    nq, D, P, b, world = 30000, 32768, 128, 32, 2
+    outs = _run_dist_gpu(tmp_path, world, nq, D, P, b, "all_to_all", "gloo", 29597, "fetch",
+                         env_extra={"QRLSH_TEST_TINY_EMIT_HINT": "1"})
     K = pipeline.max_candidates(nq)
     off, rows = qrlsh.synth_csr(nq, D, seed=0, device=DEV)
     res = pipeline.query_similarities(off, rows, ops.perm_table(ops.legacy_permutations(P, D, seed=42), DEV), b, K)
