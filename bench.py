@@ -60,7 +60,7 @@ def parse():
                          "serialise back-to-back launches and cost ~10 %% of a step when recorded on all of them)")
     ap.add_argument("--exchange", default="all_to_all", choices=["all_to_all", "all_gather"],
                     help="bucket-id exchange of the sharded path (N > 1)")
-    ap.add_argument("--sig-exchange", default="auto", choices=["auto", "fetch", "all_gather"])
+    ap.add_argument("--sig-exchange", default="auto", choices=["auto", "fetch", "all_gather", "recompute"])
     ap.add_argument("--force-dist", action="store_true", help="run the sharded driver even with one rank (testing)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] / N1 / N2 secondary timings")
     return ap.parse_args()
@@ -355,7 +355,9 @@ def main():
             "config": {"workload": workload_label(nq_total, P, b, D, world, K, nnz / max(nq_local, 1)),
                        "queries_total": nq_total, "queries_per_rank": nq_local,
                        "parallelism": "query-sharded x%d" % world,
-                       "bucket_id_exchange": (args.exchange if sharded else "none (one GPU)")},
+                       "bucket_id_exchange": ((res.stats.get("bucket_id_exchange", args.exchange) if res is not None
+                                               else args.exchange) if sharded else "none (one GPU)"),
+                       "signature_exchange": (res.stats.get("sig_exchange") if sharded and res is not None else None)},
             "pairs_scored_per_sec": round(unique_pairs * args.steps / elapsed, 1),
             "unique_pairs": unique_pairs,
             "emitted_pairs": emitted,

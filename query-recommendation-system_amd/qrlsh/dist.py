@@ -53,9 +53,24 @@ class HipBackend:
     def __init__(self):
         self.stats = {}   # which paths the kernels took (bucket_path, dedup_path, group_bits, part_bits)
 
-    def minhash(self, offsets, rows, table, b):
+    def minhash(self, offsets, rows, table, b, out=None, validate=None):
         return ops.minhash(offsets, rows, table, b=b, want_norm=True, compact=ops.can_compact(table),
-                           validate=self.validate)
+                           validate=self.validate if validate is None else validate, out=out)
+
+    def sig_dtype(self, table):
+        return torch.int16 if ops.can_compact(table) else torch.int32
+
+    def emit_pairs_bands(self, keys_all, lo, hi, r):
+        """emit_pairs for the bands [lo, hi) of every rank's [b][nql] key block in keys_all [world][b][nql],
+        read in place"""
+        world, b, nql = keys_all.shape
+        nb = hi - lo
+        pairs = ops.emit_pairs_fast(keys_all.view(-1)[lo * nql:], r, chunks=(world, nb, nql, b * nql))
+        if pairs is not None:
+            self.stats["bucket_path"] = "partition+lds"
+            self.stats["part_bits"] = ops.part_bits_for(world * nql)
+            return pairs
+        return ops.emit_pairs_any(_band_major(keys_all, lo, hi), r, self.stats)
 
     def emit_pairs(self, keys, r):
         return ops.emit_pairs_any(keys, r, self.stats)
@@ -118,6 +133,12 @@ class HipBackend:
 
     def topk_local(self, keys, dst, K, ib, q0, nql):
         return ops.topk_edges_local(keys, dst, K, ib, q0, nql)
+
+
+def _band_major(keys_all, lo, hi):
+    """bands [lo, hi) of [world][b][nql] -> band-major [hi - lo][world * nql]"""
+    world, _, nql = keys_all.shape
+    return keys_all[:, lo:hi, :].permute(1, 0, 2).reshape(hi - lo, world * nql).contiguous()
 
 
 def _owned_bands(recv, world, nb, nql):
@@ -266,8 +287,8 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
         raise AssertionError("signature length %d not divisible by b=%d" % (P, b))
     if exchange not in ("all_to_all", "all_gather"):
         raise ValueError("exchange must be 'all_to_all' or 'all_gather'")
-    if sig_exchange not in ("auto", "fetch", "all_gather"):
-        raise ValueError("sig_exchange must be 'auto', 'fetch' or 'all_gather'")
+    if sig_exchange not in ("auto", "fetch", "all_gather", "recompute"):
+        raise ValueError("sig_exchange must be 'auto', 'fetch', 'all_gather' or 'recompute'")
     r = P // b
     ib = ops.id_bits_for(nids)
     wide = ops.wide_ids(ib) if wide_ids is None else wide_ids
@@ -275,15 +296,64 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
     stats = {}
     ph = _Phases(phases, dev)
 
-    # 1. local signatures
-    sig, norm2, keys = be.minhash(offsets, rows, table, b)
-    ph.done("1_minhash")
-
-    # 2. bucket-id exchange (short, needed at once: issued before the long gather)
+    if sig_exchange == "auto":
+        # few ranks = few links, and everything a rank sends to one peer crosses ONE of them: up to four ranks the
+        # answer sets are replicated instead (64 B per query, against 256 B of signature row per scored pair plus
+        # 8 B per band of bucket ids) and every rank computes all signatures; beyond, shards stay shards
+        sig_exchange = "recompute" if 2 <= world <= 4 else "fetch"
     ranges = band_owner_ranges(b, world)
     lo, hi = ranges[rank]
     nb = hi - lo
-    if world == 1:
+    keys_all = None
+    if sig_exchange == "recompute" and world > 1:
+        # 0. answer sets of every shard: the offsets (nql + 1 each) and the row ids, padded to the largest shard
+        cnt = torch.empty((world,), dtype=torch.int64, device=dev)
+        _all_gather(cnt, torch.tensor([rows.numel()], dtype=torch.int64, device=dev), group)
+        max_nnz = max(1, int(cnt.max().item()))
+        rows_pad = rows if rows.numel() == max_nnz else torch.cat([rows, rows.new_zeros(max_nnz - rows.numel())])
+        bg = background_group(group)
+        ra = torch.empty((world, max_nnz), dtype=torch.int32, device=dev)
+        oa = torch.empty((world, nql + 1), dtype=torch.int64, device=dev)
+        h_r = _all_gather(ra.view(-1), rows_pad, bg, async_op=True)
+        h_o = _all_gather(oa.view(-1), offsets, bg, async_op=True)
+        ph.sent("0_answer_sets", (rows_pad.numel() * 4 + offsets.numel() * 8) * (world - 1))
+        # 1. signatures of ALL queries, own shard first (it runs beside the gather); every block goes straight to
+        #    its place in the replicated tables when the row blocks keep the kernel's 16-byte alignment
+        sdt = be.sig_dtype(table)
+        esz = 2 if sdt == torch.int16 else 4
+        in_place = (nql * P * esz) % 16 == 0
+        sa = torch.empty((nids, P), dtype=sdt, device=dev)
+        na = torch.empty((nids,), dtype=torch.int64, device=dev)
+        keys_all = torch.empty((world, b, nql), dtype=torch.int64, device=dev)
+
+        def shard_signatures(g, off_g, rows_g, validate):
+            blk = slice(g * nql, (g + 1) * nql)
+            if in_place:
+                be.minhash(off_g, rows_g, table, b, out=(sa[blk], na[blk], keys_all[g]), validate=validate)
+            else:
+                s_g, n_g, k_g = be.minhash(off_g, rows_g, table, b, validate=validate)
+                sa[blk].copy_(s_g)
+                na[blk].copy_(n_g)
+                keys_all[g].copy_(k_g)
+        shard_signatures(rank, offsets, rows, None)
+        h_r.wait()
+        h_o.wait()
+        for g in range(world):
+            if g != rank:
+                shard_signatures(g, oa[g], ra[g], False)      # validated by their owner
+        del ra, oa, rows_pad
+        sig, norm2 = sa[q0:q0 + nql], na[q0:q0 + nql]
+        keys = None
+        stats["bucket_id_exchange"] = "none (answer sets replicated)"
+    else:
+        # 1. local signatures
+        sig, norm2, keys = be.minhash(offsets, rows, table, b)
+    ph.done("1_minhash")
+
+    # 2. bucket-id exchange (short, needed at once: issued before the long gather)
+    if keys_all is not None:
+        recv = owned = None
+    elif world == 1:
         recv, owned = keys, None  # nothing to exchange: the local keys are the [1][b][nql] buffer
     elif exchange == "all_gather":
         allk = torch.empty((world * b, nql), dtype=torch.int64, device=dev)
@@ -301,10 +371,10 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
     ph.done("2_bucket_id_exchange")
 
     # "all_gather" of the signature rows + norms: asynchronous, on the background communicator
-    if sig_exchange == "auto":
-        sig_exchange = "all_gather" if world in (2, 3) else "fetch"
     gathered = None
-    if sig_exchange == "all_gather":
+    if keys_all is not None:
+        gathered = (sa, na, _Done(), _Done())
+    elif sig_exchange == "all_gather":
         bg = background_group(group)
         sa = torch.empty((nids, P), dtype=sig.dtype, device=dev)
         na = torch.empty((nids,), dtype=torch.int64, device=dev)
@@ -313,12 +383,14 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
     stats["sig_exchange"] = sig_exchange
 
     # 3. candidates of the owned bands over all queries
-    if nb > 0:
+    if nb > 0 and keys_all is not None:
+        emitted = be.emit_pairs_bands(keys_all, lo, hi, r)
+    elif nb > 0:
         emitted = be.emit_pairs(owned, r) if owned is not None else be.emit_pairs_chunked(recv, world, nb, nql, r)
     else:
         emitted = torch.empty((0,), dtype=torch.int64, device=dev)
     stats["emitted_pairs"] = int(emitted.numel())
-    owned = recv = None
+    owned = recv = keys_all = None
     ph.done("3_bucket_pairs")
 
     # 4. pairs -> the rank that scores them.  Duplicates across this rank's few bands are left in: the

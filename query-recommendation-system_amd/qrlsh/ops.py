@@ -122,13 +122,14 @@ def check_csr(offsets, rows, D):
         raise ValueError("malformed answer sets: " + "; ".join(what))
 
 
-def minhash(offsets, rows, table, b=None, want_norm=True, compact=False, validate=True):
+def minhash(offsets, rows, table, b=None, want_norm=True, compact=False, validate=True, out=None):
     """sig[q][p] = min over the answer set of perm_p (recommender.py:105-143), -1 if empty.
     Returns (sig [nq,P], norm2 int64 [nq] | None, keys int64 [b,nq] | None).  sig is int32, or
     with compact=True (needs can_compact(table)) the uint16 rows (torch.int16 bit patterns,
     0xFFFF = -1) that qrlsh_score_pairs reads at half the bytes; see sig_to_int32.
     validate: check the CSR first (check_csr); callers that built it with the library's own kernels
-    (answer_sets, synth_csr) may pass False."""
+    (answer_sets, synth_csr) may pass False.
+    out=(sig, norm2, keys): write into these contiguous tensors (slices of larger buffers) instead of new ones."""
     lib = _lib.load()
     _need(offsets, torch.int64, "offsets", 1)
     _need(rows, torch.int32, "rows", 1)
@@ -143,9 +144,22 @@ def minhash(offsets, rows, table, b=None, want_norm=True, compact=False, validat
         raise AssertionError("signature length %d not divisible by b=%d" % (P, b))  # lsh.py:20
     if compact and not can_compact(table):
         raise ValueError("compact signatures need D <= 65535")
-    sig = torch.empty((nq, P), dtype=torch.int16 if compact else torch.int32, device=dev)
-    norm2 = torch.empty((nq,), dtype=torch.int64, device=dev) if want_norm else None
-    keys = torch.empty((b, nq), dtype=torch.int64, device=dev) if b is not None else None
+    if out is not None:
+        sig, norm2, keys = out
+        _need(sig, torch.int16 if compact else torch.int32, "out sig", 2)
+        if tuple(sig.shape) != (nq, P) or (norm2 is not None and norm2.numel() != nq) or \
+                (keys is not None and (b is None or tuple(keys.shape) != (b, nq))):
+            raise ValueError("out buffers do not match (nq=%d, P=%d, b=%s)" % (nq, P, b))
+        if norm2 is not None:
+            _need(norm2, torch.int64, "out norm2", 1)
+        if keys is not None:
+            _need(keys, torch.int64, "out keys", 2)
+        if (b is not None) != (keys is not None) or want_norm != (norm2 is not None):
+            raise ValueError("out must hold exactly the outputs asked for")
+    else:
+        sig = torch.empty((nq, P), dtype=torch.int16 if compact else torch.int32, device=dev)
+        norm2 = torch.empty((nq,), dtype=torch.int64, device=dev) if want_norm else None
+        keys = torch.empty((b, nq), dtype=torch.int64, device=dev) if b is not None else None
     _lib.check(lib.qrlsh_minhash(_ptr(offsets), _ptr(rows), nq, _ptr(table.tab), table.code, P, table.P_stride,
                                  table.D, None if compact else _ptr(sig), _ptr(sig) if compact else None,
                                  _ptr(norm2), _ptr(keys), b if b is not None else 0, _stream()))
@@ -413,16 +427,18 @@ def emit_pairs_fast(keys, r, part_bits=None, one_pass=True, capacity=None, chunk
     no count pass runs; the output buffer is sized by `capacity` (default: 1.25 x what the last call
     of this shape emitted, else 24 pairs per query) and the call is repeated once, exactly sized,
     if that was too small.  one_pass=False is the count-then-fill form.
-    chunks=(world, nb, nql): `keys` is the [world][nb][nql] buffer a band-partitioned all-to-all delivers
-    (band t, query q at [q // nql][t][q % nql]); it is read in place (one-pass form)."""
+    chunks=(world, nb, nql[, stride]): `keys` is the [world][nb][nql] buffer a band-partitioned all-to-all delivers
+    (band t, query q at [q // nql][t][q % nql]); it is read in place (one-pass form).  stride (default nb * nql):
+    words between two ranks' chunks -- nb of each rank's b bands, read out of a [world][b][nql] buffer."""
     lib = _lib.load()
     if chunks is not None:
-        world, b, nql = chunks
+        world, b, nql = chunks[:3]
+        stride = chunks[3] if len(chunks) > 3 else b * nql     # words between the chunks of two ranks
         nq = world * nql
         _need(keys, torch.int64, "keys")
-        if keys.numel() != world * b * nql or not one_pass:
-            raise ValueError("chunked keys: need world * nb * nql words and the one-pass form")
-        layout = (nql, b * nql, nql)
+        if stride < b * nql or keys.numel() < (world - 1) * stride + b * nql or not one_pass:
+            raise ValueError("chunked keys: need (world - 1) * stride + nb * nql words and the one-pass form")
+        layout = (nql, stride, nql)
     else:
         _need(keys, torch.int64, "keys", 2)
         b, nq = keys.shape

@@ -30,8 +30,14 @@ def _t(a):
 class OracleBackend:
     """numpy / C-oracle implementation of the backend interface on CPU tensors (tests only)."""
 
-    def minhash(self, offsets, rows, table, b):
-        sig = O.minhash(offsets.numpy(), rows.numpy(), table.perms)
+    def sig_dtype(self, table):
+        return torch.int32
+
+    def emit_pairs_bands(self, keys_all, lo, hi, r):
+        return self.emit_pairs(qdist._band_major(keys_all, lo, hi), r)
+
+    def minhash(self, offsets, rows, table, b, out=None, validate=None):
+        sig = O.minhash(np.ascontiguousarray(offsets.numpy()), np.ascontiguousarray(rows.numpy()), table.perms)
         P = sig.shape[1]
         if P // b <= 4:
             keys = O.band_keys(sig, b).T.copy()
@@ -44,6 +50,11 @@ class OracleBackend:
             h[np.all(lo == 0xFFFF, axis=2)] = np.uint64(0xFFFFFFFFFFFFFFFF)
             keys = h.T.copy()
         norm2 = (sig.astype(np.int64) ** 2).sum(1)
+        if out is not None:
+            out[0].copy_(_t(sig))
+            out[1].copy_(_t(norm2))
+            out[2].copy_(_t(keys.view(np.int64)))
+            return out
         return _t(sig), _t(norm2), _t(keys.view(np.int64))
 
     def emit_pairs(self, keys, r):

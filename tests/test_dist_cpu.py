@@ -31,6 +31,10 @@ def _run(tmp_path, world, nq, D, P, b, mode, port, extra=()):
                                                   (3, "all_to_all", 8, ("sig=all_gather",), 601),   # 601 = 3 * 201 - 2:
                                                   (3, "all_to_all", 8, ("sig=fetch",), 601),        # padded last shard
                                                   (4, "all_gather", 8, ("sig=fetch",), 598),
+                                                  (2, "all_to_all", 8, ("sig=recompute",), 600),    # answer sets replicated,
+                                                  (3, "all_to_all", 8, ("sig=recompute",), 601),    # no bucket-id / row exchange
+                                                  (4, "all_to_all", 8, (), 598),                    # (auto up to 4 ranks)
+                                                  (2, "all_to_all", 4, ("wide", "sig=recompute"), 599),
                                                   (8, "all_to_all", 8, ("sig=fetch",), 603),        # the driver's N = 8:
                                                   (8, "all_to_all", 32, ("sig=fetch",), 1001),      # one band / four bands per rank
                                                   (2, "all_to_all", 4, ("wide", "sig=fetch"), 600),
