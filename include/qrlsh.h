@@ -153,10 +153,12 @@ int qrlsh_bucket_pairs_fill(const uint64_t *part_keys, const uint32_t *part_ids,
  * whether or not they fitted (if it exceeds capacity: allocate that many and call again), [1] the same
  * oversized-part flag as qrlsh_bucket_pairs_count.  The pairs come out in no particular order.
  * part_keys / part_ids must hold qrlsh_bucket_part_words(nq, b, part_bits) words and, for part_bits > 8,
- * tmp_keys / tmp_ids qrlsh_bucket_tmp_words(...): the partition is ONE kernel per 8 bits that gives every
- * part a fixed region and reserves room in it with an atomic per (tile, part) -- no histogram pass, no
- * scan, no bounds search -- and those regions need more room than the b * nq records themselves (a part
- * outgrowing its region raises the same overflow flag). */
+ * tmp_keys / tmp_ids qrlsh_bucket_tmp_words(...): the partition is ONE kernel per level (one level for
+ * part_bits = 8, two of about part_bits / 2 bits each beyond) that gives every part a fixed region and reserves
+ * room in it with an atomic per (tile, part) -- no histogram pass, no scan, no bounds search -- and those regions
+ * need more room than the b * nq records themselves (a part outgrowing its region raises the same overflow
+ * flag).  These buffers are scratch: what they hold afterwards is mix64(key) (a bijection of the keys, which is
+ * all the pairing needs), not the keys, and the records of empty bands are gone. */
 size_t qrlsh_bucket_part_words(int64_t nq, int32_t b, int32_t part_bits);
 size_t qrlsh_bucket_tmp_words(int64_t nq, int32_t b, int32_t part_bits);
 int qrlsh_bucket_pairs_emit(const uint64_t *keys, uint64_t *part_keys, uint32_t *part_ids,
@@ -169,7 +171,8 @@ int qrlsh_bucket_pairs_emit(const uint64_t *keys, uint64_t *part_keys, uint32_t 
  *     keys[(q / key_chunk) * key_chunk_stride + t * key_band_stride + q % key_chunk]
  * -- what a band-partitioned all-to-all delivers ([rank][band][queries of that rank]: key_chunk = queries
  * per rank, key_band_stride = key_chunk, key_chunk_stride = bands * key_chunk), so the multi-GPU driver
- * needs no transposing copy.  key_chunk = 0: plain [b][nq].  Chunked keys need nq <= 2^24. */
+ * needs no transposing copy; key_chunk_stride may exceed bands * key_chunk (a band range read out of a buffer
+ * that holds more bands per rank).  key_chunk = 0: plain [b][nq].  Chunked keys need nq < 2^32. */
 int qrlsh_bucket_pairs_emit_chunked(const uint64_t *keys, int64_t key_chunk, int64_t key_chunk_stride,
                                     int64_t key_band_stride, uint64_t *part_keys, uint32_t *part_ids,
                                     uint64_t *tmp_keys, uint32_t *tmp_ids, int64_t nq, int32_t b, int32_t r,
