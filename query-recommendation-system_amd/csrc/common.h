@@ -88,6 +88,22 @@ __device__ static inline uint64_t qr_make_key(const uint16_t *s, int r) {
   return h == ~0ull ? h - 1 : h;
 }
 
+// Streams that are written (or read) once and not touched again by the same kernel go past the caches' normal
+// allocation (non-temporal hint), leaving L2 to the data the kernel re-reads.  Per kernel, decided by
+// measurement (tools/ab_flags.sh, same box): QR_NT_MINHASH (answer-set ids in, signatures / keys / norms out,
+// beside the table gather): 3.89 -> 3.61 ms at 10 M queries.  The same hint on the scoring kernel's pair /
+// score / edge streams made it slower (3.80 -> 3.90) and is not used.
+#ifndef QR_NT_MINHASH
+#define QR_NT_MINHASH 1
+#endif
+template <bool NT, typename T> __device__ static inline void qr_store(T v, T *p) {
+  if (NT) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+template <bool NT, typename T> __device__ static inline T qr_load(const T *p) {
+  return NT ? __builtin_nontemporal_load(p) : *p;
+}
+
 __device__ static inline int lane_id() { return threadIdx.x & (WAVE - 1); }
 
 // wave-level inclusive scan of a u64 via shuffles

@@ -63,7 +63,7 @@ __device__ static inline int64_t store_sig(typename TabVec<TabT>::type acc, int 
         u16x8 v;
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (uint16_t)out[e % VEC];
-        *reinterpret_cast<u16x8 *>(d16) = v;
+        qr_store<QR_NT_MINHASH != 0>(v, reinterpret_cast<u16x8 *>(d16));
       } else {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) d16[e] = (uint16_t)out[e];
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void minhash_group_kernel(const int64_t *__res
   int64_t offs = 0;
   {
     const int64_t qi = qw0 + lane;
-    if (lane <= MH_QPW) offs = offsets[qi < nq ? qi : nq];
+    if (lane <= MH_QPW) offs = qr_load<QR_NT_MINHASH != 0>(&offsets[qi < nq ? qi : nq]);
   }
   auto batch_lo = [&](int batch, int &n, int &qlw) -> int64_t {
     qlw = batch * G + g;  // the wave-local query this group works on in this batch
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void minhash_group_kernel(const int64_t *__res
   };
   int n_cur, qlw_cur;
   int64_t lo_cur = batch_lo(0, n_cur, qlw_cur);
-  int my_cur = (lig < n_cur) ? rows[lo_cur + lig] : 0;
+  int my_cur = (lig < n_cur) ? qr_load<QR_NT_MINHASH != 0>(&rows[lo_cur + lig]) : 0;
 
 #pragma unroll 1
   for (int batch = 0; batch < MH_QPW / G; ++batch) {
@@ -246,14 +246,14 @@ __global__ __launch_bounds__(256) void minhash_group_kernel(const int64_t *__res
     int64_t lo_nxt = 0;
     if (batch + 1 < MH_QPW / G) {
       lo_nxt = batch_lo(batch + 1, n_nxt, qlw_nxt);
-      if (lig < n_nxt) my_nxt = rows[lo_nxt + lig];
+      if (lig < n_nxt) my_nxt = qr_load<QR_NT_MINHASH != 0>(&rows[lo_nxt + lig]);
     }
     VecT acc = TabVec<TabT>::init();
     int my = my_cur;
     // the MH_CH gathers of a step sit in their own exec regions with the min after all of them, so
     // they are independent loads in flight together, not MH_CH load -> wait -> min round trips
     for (int base = 0; __any(base < n_cur); base += LPR) {
-      const int my_after = (base + LPR + lig < n_cur) ? rows[lo_cur + base + LPR + lig] : 0;
+      const int my_after = (base + LPR + lig < n_cur) ? qr_load<QR_NT_MINHASH != 0>(&rows[lo_cur + base + LPR + lig]) : 0;
 #pragma unroll
       for (int sub = 0; sub < LPR; sub += MH_CH) {
         if (sub > 0 && !__any(base + sub < n_cur)) break;  // wave-uniform
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void minhash_group_kernel(const int64_t *__res
       if (norm2) {
 #pragma unroll
         for (int m = 1; m < LPR; m <<= 1) nrm += __shfl_xor(nrm, m, WAVE);
-        if (lig == 0) norm2[q] = nrm;
+        if (lig == 0) qr_store<QR_NT_MINHASH != 0>(nrm, &norm2[q]);
       }
     } else if (norm2) {
 #pragma unroll
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void minhash_group_kernel(const int64_t *__res
     for (int idx = threadIdx.x; idx < QPB * b; idx += blockDim.x) {
       const int ql = idx % QPB, band = idx / QPB;
       if (ql < nql) {
-        keys[(size_t)band * nq + q0 + ql] = qr_make_key(s16 + ql * ldk + band * r, r);
+        qr_store<QR_NT_MINHASH != 0>(qr_make_key(s16 + ql * ldk + band * r, r), &keys[(size_t)band * nq + q0 + ql]);
       }
     }
   }
