@@ -368,13 +368,19 @@ int qrlsh_answer_sets_compact(const int32_t *slots, const int64_t *offsets, int6
  * order (what numba's nopython np.sum does where numba is installed; unpinned here).
  * Limits: ku <= 64 (QRLSH_EINVAL otherwise); a query with more than 64 neighbours sets *too_long_out
  * (device uint32, required) to 1 and its column is not to be trusted -- the caller reads the flag back.
+ * kq > 0 with a workspace of qrlsh_predict_workspace_bytes(nq, kq): the caller states the longest query list
+ * (kq <= 64; a longer one sets the flag) and the lists are first transposed to [kq][nq] there, so that the
+ * sweep over the cells reads them with consecutive lanes (21.7 against 32.1 ms on the bench shape); kq = 0 /
+ * workspace = NULL: the lists are read in their CSR form.  Same results either way.
  */
 #define QRLSH_SUM_PAIRWISE 0
 #define QRLSH_SUM_SEQUENTIAL 1
+size_t qrlsh_predict_workspace_bytes(int64_t nq, int32_t kq);
 int qrlsh_predict(const int32_t *ratings, int64_t nu, int64_t nq, const int64_t *q_off,
                   const int32_t *q_idx, const double *q_val, const int32_t *u_idx, const double *u_val,
                   int32_t ku, double query_weight, double user_weight, double default_mean,
-                  int32_t sum_order, int32_t *out, uint32_t *too_long_out, void *stream);
+                  int32_t sum_order, int32_t *out, uint32_t *too_long_out, int32_t kq, void *workspace,
+                  size_t workspace_bytes, void *stream);
 
 /* ---- N4: user similarity, the part after the clustering ----------------------------------------
  * Recommender.compute_userSimilarities, recommender.py:263-288: inside a cluster every user's row is centred on

@@ -63,6 +63,23 @@ struct Pairwise8 {
     }
     ++t;
   }
+  // elements [k0, k0 + 8) of the list at once (k0 a multiple of 8; v[u] of elements past n are ignored): the
+  // accumulator of element k0 + u is r<u>, known at compile time -- no per-element dispatch
+  __device__ void add8(const double (&v)[8], int k0) {
+    if (!seq && k0 < body) {   // a whole chunk of the round-robin part (body is a multiple of 8)
+      if (k0 == 0) {
+        r0 = v[0]; r1 = v[1]; r2 = v[2]; r3 = v[3]; r4 = v[4]; r5 = v[5]; r6 = v[6]; r7 = v[7];
+      } else {
+        r0 += v[0]; r1 += v[1]; r2 += v[2]; r3 += v[3]; r4 += v[4]; r5 += v[5]; r6 += v[6]; r7 += v[7];
+      }
+      if (k0 + 8 == body) res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    } else {
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (k0 + u < n) res += v[u];
+    }
+    t = k0 + 8;
+  }
   __device__ double end() const { return res; }
 };
 
@@ -74,23 +91,52 @@ __device__ static inline double weighted_average(int n, bool sequential, RatingA
   Pairwise8 prod;
   prod.begin(n, sequential);
   unsigned long long nz = 0;
-  for (int k = 0; k < n; ++k) {
-    const int32_t r = rating(k);
-    prod.add((double)r * sim(k));
-    if (r != 0) nz |= 1ull << k;
+  // eight neighbours at a time: their list entries, then their ratings, are independent loads in flight together
+  // (a dependent index -> rating round trip per neighbour otherwise); the additions keep the list order
+  for (int k0 = 0; k0 < n; k0 += 8) {
+    int32_t r[8];
+    double sv[8], pv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      r[u] = 0;
+      sv[u] = 0.0;
+      if (k0 + u < n) {
+        sv[u] = sim(k0 + u);
+        r[u] = rating(k0 + u);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      pv[u] = (double)r[u] * sv[u];
+      if (r[u] != 0) nz |= 1ull << (k0 + u);   // r[u] = 0 past the end
+    }
+    prod.add8(pv, k0);
   }
+  // the weights of the rated neighbours, in list order, eight at a time as well
   Pairwise8 w;
-  w.begin(__popcll(nz), sequential);
-  while (nz) {
-    const int k = __ffsll((long long)nz) - 1;
-    w.add(sim(k));
-    nz &= nz - 1;
+  const int m = __popcll(nz);
+  w.begin(m, sequential);
+  for (int k0 = 0; k0 < m; k0 += 8) {
+    double wv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      wv[u] = 0.0;
+      if (nz) {
+        wv[u] = sim(__ffsll((long long)nz) - 1);
+        nz &= nz - 1;
+      }
+    }
+    w.add8(wv, k0);
   }
   const double wsum = w.end();
   if (wsum == 0.0) return 0.0;
   return prod.end() / wsum;
 }
 
+// TL: the query neighbour lists come transposed and padded, idx_t / val_t [kq][nq] (entry k of query j at
+// k * nq + j; predict_lists_transpose_kernel): consecutive lanes = consecutive queries then read consecutive words,
+// where the CSR form costs a separate cache line per lane for every list entry (q_idx / q_val = idx_t / val_t).
+template <bool TL>
 __global__ __launch_bounds__(256) void predict_kernel(const int32_t *__restrict__ ratings, int64_t nu, int64_t nq,
                                                       const int64_t *__restrict__ q_off,
                                                       const int32_t *__restrict__ q_idx,
@@ -111,10 +157,14 @@ __global__ __launch_bounds__(256) void predict_kernel(const int32_t *__restrict_
   }
   // query side: neighbours of query j, this user's ratings of them
   const int64_t lo = q_off[j];
-  const int n = (int)(q_off[j + 1] - lo);   // <= PRED_MAXK: checked by the host
+  const int n = (int)(q_off[j + 1] - lo);   // <= PRED_MAXK (and <= kq): checked by the host
   const int32_t *row = ratings + i * nq;
-  const double qp = weighted_average(
-      n, sequential != 0, [&](int k) { return row[q_idx[lo + k]]; }, [&](int k) { return q_val[lo + k]; });
+  const double qp = TL ? weighted_average(
+                             n, sequential != 0, [&](int k) { return row[q_idx[(int64_t)k * nq + j]]; },
+                             [&](int k) { return q_val[(int64_t)k * nq + j]; })
+                       : weighted_average(
+                             n, sequential != 0, [&](int k) { return row[q_idx[lo + k]]; },
+                             [&](int k) { return q_val[lo + k]; });
   // user side: neighbours of user i (-1 padded), their ratings of query j
   const int32_t *ui = u_idx + i * ku;
   const double *uv = u_val + i * ku;
@@ -132,16 +182,37 @@ __global__ __launch_bounds__(256) void predict_kernel(const int32_t *__restrict_
 
 // longest query neighbour list (host pre-check of the 64-entry limit without a read-back: the kernel below
 // raises a device flag, the caller reads it together with the result)
-__global__ __launch_bounds__(256) void predict_check_kernel(const int64_t *__restrict__ q_off, int64_t nq,
+__global__ __launch_bounds__(256) void predict_check_kernel(const int64_t *__restrict__ q_off, int64_t nq, int maxlen,
                                                             uint32_t *__restrict__ too_long) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < nq && q_off[j + 1] - q_off[j] > PRED_MAXK) atomicOr(too_long, 1u);
+  if (j < nq && q_off[j + 1] - q_off[j] > maxlen) atomicOr(too_long, 1u);
+}
+
+// CSR neighbour lists -> [kq][nq], coalesced writes (one thread per output word; -1 / 0.0 past a list's end)
+__global__ __launch_bounds__(256) void predict_lists_transpose_kernel(const int64_t *__restrict__ q_off,
+                                                                      const int32_t *__restrict__ q_idx,
+                                                                      const double *__restrict__ q_val, int64_t nq,
+                                                                      int kq, int32_t *__restrict__ idx_t,
+                                                                      double *__restrict__ val_t) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)kq * nq) return;
+  const int64_t k = t / nq, j = t - k * nq;
+  const int64_t lo = q_off[j];
+  const bool in = k < q_off[j + 1] - lo;
+  idx_t[t] = in ? q_idx[lo + k] : -1;
+  val_t[t] = in ? q_val[lo + k] : 0.0;
+}
+
+QRLSH_EXPORT size_t qrlsh_predict_workspace_bytes(int64_t nq, int32_t kq) {
+  if (nq <= 0 || kq <= 0) return 0;
+  return (size_t)kq * (size_t)nq * (sizeof(double) + sizeof(int32_t)) + 16;
 }
 
 QRLSH_EXPORT int qrlsh_predict(const int32_t *ratings, int64_t nu, int64_t nq, const int64_t *q_off,
                                const int32_t *q_idx, const double *q_val, const int32_t *u_idx, const double *u_val,
                                int32_t ku, double query_weight, double user_weight, double default_mean,
-                               int32_t sum_order, int32_t *out, uint32_t *too_long_out, void *stream) {
+                               int32_t sum_order, int32_t *out, uint32_t *too_long_out, int32_t kq, void *workspace,
+                               size_t workspace_bytes, void *stream) {
   QR_CHECK_ARG(nu >= 0 && nq >= 0 && ku >= 0 && ku <= PRED_MAXK, "qrlsh_predict: bad sizes nu=%lld nq=%lld ku=%d (<= %d)",
                (long long)nu, (long long)nq, ku, PRED_MAXK);
   QR_CHECK_ARG(sum_order == QRLSH_SUM_PAIRWISE || sum_order == QRLSH_SUM_SEQUENTIAL, "qrlsh_predict: bad sum_order %d",
@@ -154,11 +225,26 @@ QRLSH_EXPORT int qrlsh_predict(const int32_t *ratings, int64_t nu, int64_t nq, c
   }
   if (nu == 0 || nq == 0) return QRLSH_OK;
   QR_CHECK_ARG(ratings && q_off && out && (ku == 0 || (u_idx && u_val)), "qrlsh_predict: null pointer");
+  const bool tl = kq > 0 && workspace != nullptr;
+  QR_CHECK_ARG(kq >= 0 && kq <= PRED_MAXK && (!tl || workspace_bytes >= qrlsh_predict_workspace_bytes(nq, kq)),
+               "qrlsh_predict: kq=%d (<= %d) needs %zu workspace bytes, got %zu", kq, PRED_MAXK,
+               qrlsh_predict_workspace_bytes(nq, kq), workspace_bytes);
   QR_LAUNCH("predict_check", predict_check_kernel, dim3((unsigned)ceil_div64(nq, 256)), dim3(256), 0, st, q_off, nq,
-            too_long_out);
-  QR_LAUNCH("predict", predict_kernel, dim3((unsigned)ceil_div64(nu * nq, 256)), dim3(256), 0, st, ratings, nu, nq,
-            q_off, q_idx, q_val, u_idx, u_val, ku, query_weight, user_weight, default_mean,
-            (int)(sum_order == QRLSH_SUM_SEQUENTIAL), out);
+            tl ? (int)kq : PRED_MAXK, too_long_out);
+  if (tl) {
+    // lists transposed once ([kq][nq], doubles first: 8-byte aligned), then read coalesced by every user's sweep
+    double *val_t = static_cast<double *>(workspace);
+    int32_t *idx_t = reinterpret_cast<int32_t *>(val_t + (size_t)kq * nq);
+    QR_LAUNCH("predict_lists", predict_lists_transpose_kernel, dim3((unsigned)ceil_div64((int64_t)kq * nq, 256)),
+              dim3(256), 0, st, q_off, q_idx, q_val, nq, (int)kq, idx_t, val_t);
+    QR_LAUNCH("predict", predict_kernel<true>, dim3((unsigned)ceil_div64(nu * nq, 256)), dim3(256), 0, st, ratings, nu,
+              nq, q_off, (const int32_t *)idx_t, (const double *)val_t, u_idx, u_val, ku, query_weight, user_weight,
+              default_mean, (int)(sum_order == QRLSH_SUM_SEQUENTIAL), out);
+  } else {
+    QR_LAUNCH("predict", predict_kernel<false>, dim3((unsigned)ceil_div64(nu * nq, 256)), dim3(256), 0, st, ratings, nu,
+              nq, q_off, q_idx, q_val, u_idx, u_val, ku, query_weight, user_weight, default_mean,
+              (int)(sum_order == QRLSH_SUM_SEQUENTIAL), out);
+  }
   QR_LAUNCH_CHECK("qrlsh_predict");
   return QRLSH_OK;
 }

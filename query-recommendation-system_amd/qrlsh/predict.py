@@ -17,12 +17,15 @@ MAX_NEIGHBOURS = 64   # PRED_MAXK in csrc/predict.hip
 
 
 def fill_predictions(ratings, q_src, q_dst, q_milli, user_sims, query_weight=QUERY_WEIGHT,
-                     user_weight=USER_WEIGHT, default_mean=DEFAULT_MEAN, device="cuda", sum_order="pairwise"):
+                     user_weight=USER_WEIGHT, default_mean=DEFAULT_MEAN, device="cuda", sum_order="pairwise",
+                     transpose_lists=True):
     """ratings: (nu, nq) integer array / tensor, 0 = missing.
     q_src/q_dst/q_milli: the hot path's top-K COO (sorted by src; value = milli / 1000).
     user_sims: {u: {'indexes', 'values'}} as compute_userSimilarities returns it.
     sum_order: "pairwise" (numpy's np.sum order: the reference as plain Python, what the fixtures pin) or
     "sequential" (numba's nopython np.sum: the reference where numba is installed; unpinned).
+    transpose_lists: let the kernel sweep the query lists transposed to [longest list][nq] (coalesced; one extra
+    read-back for the longest list) instead of their CSR form; same results.
     -> int32 device tensor (nu, nq): finalPredictions of recommender.py:301-331.
     Raises ValueError when a neighbour list is longer than 64 (K = round(log_1.5 n) stays below 52 for any
     n < 1e9; only an overridden max_candidates gets there)."""
@@ -52,10 +55,16 @@ def fill_predictions(ratings, q_src, q_dst, q_milli, user_sims, query_weight=QUE
     u_val = torch.from_numpy(uv).to(device)
     out = torch.empty((nu, nq), dtype=torch.int32, device=device)
     too_long = torch.zeros((1,), dtype=torch.int32, device=device)
+    # the longest query list (one read-back): the kernel sweeps the lists transposed to [kq][nq]
+    kq = int(counts.max().item()) if (nq and transpose_lists) else 0
+    if kq > MAX_NEIGHBOURS:
+        raise ValueError("a query has more than %d neighbours (%d; max_candidates overridden?); the prediction kernel "
+                         "handles at most %d" % (MAX_NEIGHBOURS, kq, MAX_NEIGHBOURS))
+    ws = torch.empty((max(int(lib.qrlsh_predict_workspace_bytes(nq, kq)), 16),), dtype=torch.uint8, device=device)
     _lib.check(lib.qrlsh_predict(_ptr(r), nu, nq, _ptr(q_off), _ptr(q_idx), _ptr(q_val), _ptr(u_idx), _ptr(u_val),
                                  ui.shape[1] if ku else 0, float(query_weight), float(user_weight), float(default_mean),
                                  _lib.SUM_SEQUENTIAL if sum_order == "sequential" else _lib.SUM_PAIRWISE,
-                                 _ptr(out), _ptr(too_long), _stream()))
+                                 _ptr(out), _ptr(too_long), kq, _ptr(ws) if kq else None, ws.numel(), _stream()))
     if int(too_long.item()):
         raise ValueError("a query has more than %d neighbours (max_candidates overridden?); the prediction kernel "
                          "handles at most %d" % (MAX_NEIGHBOURS, MAX_NEIGHBOURS))

@@ -1119,14 +1119,16 @@ def test_prediction_kernel_equals_oracle_on_random_inputs():
     for (nu, nq, Kq, Ku, fill) in [(7, 9, 3, 2, 0.5), (40, 60, 17, 11, 0.3), (25, 30, 20, 12, 0.8), (5, 5, 1, 1, 0.0),
                                    (70, 90, 64, 64, 0.6), (33, 80, 41, 7, 0.9)]:
         ratings, qs, us, coo = _random_prediction_case(rng, nu, nq, Kq, Ku, fill)
-        out = predict.fill_predictions(ratings, *coo, us, device=DEV)
-        assert np.array_equal(out.cpu().numpy(), O.predict_scores(ratings, qs, us))
-        out = predict.fill_predictions(ratings, *coo, us, device=DEV, sum_order="sequential")
-        assert np.array_equal(out.cpu().numpy(), O.predict_scores(ratings, qs, us, summation=seq_sum))
+        for tl in (True, False):     # query lists transposed to [longest][nq] (default) / read in their CSR form
+            out = predict.fill_predictions(ratings, *coo, us, device=DEV, transpose_lists=tl)
+            assert np.array_equal(out.cpu().numpy(), O.predict_scores(ratings, qs, us))
+            out = predict.fill_predictions(ratings, *coo, us, device=DEV, sum_order="sequential", transpose_lists=tl)
+            assert np.array_equal(out.cpu().numpy(), O.predict_scores(ratings, qs, us, summation=seq_sum))
     ratings, qs, us, coo = _random_prediction_case(rng, 80, 100, 80, 10, 0.5)
     assert max(len(v["indexes"]) for v in qs.values()) > 64
-    with pytest.raises(ValueError, match="more than 64 neighbours"):
-        predict.fill_predictions(ratings, *coo, us, device=DEV)
+    for tl in (True, False):         # refused on the host / by the kernel's flag
+        with pytest.raises(ValueError, match="more than 64 neighbours"):
+            predict.fill_predictions(ratings, *coo, us, device=DEV, transpose_lists=tl)
     ratings, qs, us, coo = _random_prediction_case(rng, 80, 100, 10, 80, 0.5)
     with pytest.raises(ValueError, match="at most 64"):
         predict.fill_predictions(ratings, *coo, us, device=DEV)
