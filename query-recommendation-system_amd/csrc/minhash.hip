@@ -324,10 +324,32 @@ __global__ __launch_bounds__(256) void band_keys_kernel(const int32_t *__restric
   }
 }
 
-// exact squared L2 norm of every signature row; one wave per row.
+// exact squared L2 norm of every signature row; one wave per row, or (rows of thousands of columns: N4's rating
+// rows) one workgroup per row.
+template <bool WG_PER_ROW>
 __global__ __launch_bounds__(256) void row_norms_kernel(const int32_t *__restrict__ sig, int64_t nq, int P,
                                                         int64_t *__restrict__ norm2) {
   const int lane = threadIdx.x & (WAVE - 1);
+  if (WG_PER_ROW) {
+    __shared__ int64_t part[256 / WAVE];
+    for (int64_t q = blockIdx.x; q < nq; q += gridDim.x) {
+      const int32_t *s = sig + (size_t)q * P;
+      int64_t acc = 0;
+      for (int c = threadIdx.x; c < P; c += 256) acc += (int64_t)s[c] * s[c];
+#pragma unroll
+      for (int m = 1; m < WAVE; m <<= 1) acc += __shfl_xor(acc, m, WAVE);
+      if (lane == 0) part[threadIdx.x >> 6] = acc;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        int64_t t = 0;
+#pragma unroll
+        for (int i = 0; i < 256 / WAVE; ++i) t += part[i];
+        norm2[q] = t;
+      }
+      __syncthreads();
+    }
+    return;
+  }
   const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t q = wid; q < nq; q += nw) {
@@ -458,9 +480,14 @@ QRLSH_EXPORT int qrlsh_band_keys(const int32_t *sig, int64_t nq, int32_t P, int3
 QRLSH_EXPORT int qrlsh_row_norms(const int32_t *sig, int64_t nq, int32_t P, int64_t *norm2_out, void *stream) {
   QR_CHECK_ARG(nq >= 0 && P > 0 && (nq == 0 || (sig && norm2_out)), "qrlsh_row_norms: bad arguments");
   if (nq == 0) return QRLSH_OK;
-  const int64_t blocks = ceil_div64(nq, 4);
-  QR_LAUNCH("row_norms", row_norms_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), sig, nq, P, norm2_out);
+  if (P >= 2048) {
+    QR_LAUNCH("row_norms", row_norms_kernel<true>, dim3((unsigned)(nq < 65536 ? nq : 65536)), dim3(256), 0,
+              static_cast<hipStream_t>(stream), sig, nq, P, norm2_out);
+  } else {
+    const int64_t blocks = ceil_div64(nq, 4);
+    QR_LAUNCH("row_norms", row_norms_kernel<false>, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0,
+              static_cast<hipStream_t>(stream), sig, nq, P, norm2_out);
+  }
   QR_LAUNCH_CHECK("qrlsh_row_norms");
   return QRLSH_OK;
 }
