@@ -62,6 +62,10 @@ def parse():
                     help="bucket-id exchange of the sharded path (N > 1)")
     ap.add_argument("--sig-exchange", default="auto", choices=["auto", "fetch", "all_gather", "recompute"])
     ap.add_argument("--force-dist", action="store_true", help="run the sharded driver even with one rank (testing)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + --share-gpu: rehearse the N > 1 code path with all ranks on ONE GPU (testing; the "
+                         "collectives are staged through the host, the timings mean nothing)")
+    ap.add_argument("--share-gpu", action="store_true", help="every rank uses cuda:0 (testing, with --dist-backend gloo)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] / N1 / N2 secondary timings")
     return ap.parse_args()
 
@@ -180,6 +184,8 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (WORLD_SIZE=%d)" % (args.gpus, world))
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -189,7 +195,10 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29544")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if args.dist_backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     import qrlsh
     from qrlsh import ops, pipeline, _lib
@@ -255,11 +264,12 @@ def main():
         prof = _lib.prof_report()
         _lib.prof_enable(False)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        rdev = dev if args.dist_backend == "nccl" else torch.device("cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         cnt = torch.tensor([res.pairs.numel(), res.stats.get("emitted_pairs", 0), res.src.numel()], dtype=torch.int64,
-                           device=dev)
+                           device=rdev)
         dist.all_reduce(cnt)
         unique_pairs, emitted, kept_total = (int(x) for x in cnt.tolist())
     else:
