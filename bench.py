@@ -170,8 +170,31 @@ def load_traffic(nq_total, P, b):
 PRIME_STEPS = 3   # untimed setup steps before the warmup (see main)
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N
+    bench.py <same arguments>` as a child process (one rank per GPU over RCCL) and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:           # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("bench.py: WORLD_SIZE unset, launching %d ranks: %s\n" % (n, " ".join(cmd)))
+    sys.stderr.flush()
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves, as CHILD processes, before this process has
+        # made any GPU call (a process that touched the GPU must never be replaced by exec); rank 0's JSON line
+        # reaches our stdout through the inherited descriptor and the launcher's return code becomes ours
+        sys.exit(self_launch(args.gpus))
     # RCCL (and other native libraries) print banners on fd 1 when a communicator comes up; the
     # contract is ONE JSON line on stdout, so everything else is sent to stderr for the whole run
     # and the JSON goes to the saved descriptor at the end.
@@ -182,8 +205,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (WORLD_SIZE=%d)" % (args.gpus, world))
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: running with the launcher's %d rank(s)\n"
+                         % (args.gpus, world, world))
     if args.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)

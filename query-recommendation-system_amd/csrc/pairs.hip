@@ -760,7 +760,7 @@ __device__ static inline bool region_finish(const uint64_t *__restrict__ in, int
     ndist = 0;
   }
   __syncthreads();
-  const uint32_t gmask = (1u << gbits) - 1u, jmask = (1u << jbits) - 1u;  // jbits <= 31 here (checked by the host)
+  const uint32_t gmask = (1u << gbits) - 1u, jmask = (1u << jbits) - 1u;  // jbits <= 31 (qrlsh_region_unique_count refuses 32)
   // 1. stream the words into the hash set, four independent loads in flight per thread
   for (int64_t p0 = s0 + t; p0 < s1; p0 += 4 * RG_THREADS) {
     uint64_t x[4];
@@ -964,9 +964,11 @@ QRLSH_EXPORT int qrlsh_region_unique_count(const uint64_t *grouped, int64_t n, i
   QR_CHECK_ARG(n >= 0 && total_overflow_out && nids > 0 && nids <= (1ll << 32), "qrlsh_region_unique_count: bad arguments");
   // the 32-bit value (i's low bits, j) must never be the empty-slot marker 0xFFFFFFFF: either it has a spare
   // bit, or the largest j (nids - 1) is not all ones
-  QR_CHECK_ARG(group_bits >= 0 && group_bits <= 8 && id_bits >= 1 && id_bits <= 32 && nids <= (1ll << id_bits) &&
+  // (id_bits <= 31: the kernels build the j mask as (1u << id_bits) - 1)
+  QR_CHECK_ARG(group_bits >= 0 && group_bits <= 8 && id_bits >= 1 && id_bits <= 31 && nids <= (1ll << id_bits) &&
                    (group_bits + id_bits < 32 || (group_bits + id_bits == 32 && nids < (1ll << id_bits))),
-               "qrlsh_region_unique_count: group_bits=%d / id_bits=%d (need group_bits <= 8, group_bits + id_bits <= 32)",
+               "qrlsh_region_unique_count: group_bits=%d / id_bits=%d (need group_bits <= 8, id_bits <= 31, group_bits + "
+               "id_bits <= 32)",
                group_bits, id_bits);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (hipMemsetAsync(total_overflow_out, 0, 2 * sizeof(uint64_t), st) != hipSuccess) {

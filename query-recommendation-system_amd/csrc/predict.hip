@@ -143,7 +143,8 @@ __global__ __launch_bounds__(256) void predict_kernel(const int32_t *__restrict_
                                                       const double *__restrict__ q_val,
                                                       const int32_t *__restrict__ u_idx,
                                                       const double *__restrict__ u_val, int ku, double qw, double uw,
-                                                      double dmean, int sequential, int32_t *__restrict__ out) {
+                                                      double dmean, int sequential, int nlimit,
+                                                      int32_t *__restrict__ out) {
   // consecutive lanes = consecutive queries of ONE user: the user-side gathers ratings[u][j] are coalesced
   // across the wave and the user's neighbour list is wave-uniform; the query-side gathers stay inside the
   // user's own row (4 nq bytes, cache-resident while the row's workgroups run)
@@ -157,7 +158,14 @@ __global__ __launch_bounds__(256) void predict_kernel(const int32_t *__restrict_
   }
   // query side: neighbours of query j, this user's ratings of them
   const int64_t lo = q_off[j];
-  const int n = (int)(q_off[j + 1] - lo);   // <= PRED_MAXK (and <= kq): checked by the host
+  const int64_t n64 = q_off[j + 1] - lo;
+  // a list longer than the limit (PRED_MAXK entries, or the kq rows of the transposed workspace) is never walked:
+  // predict_check_kernel has raised *too_long_out for it, the cell gets 0 and the caller discards the result
+  if (n64 < 0 || n64 > nlimit) {
+    out[cell] = 0;
+    return;
+  }
+  const int n = (int)n64;
   const int32_t *row = ratings + i * nq;
   const double qp = TL ? weighted_average(
                              n, sequential != 0, [&](int k) { return row[q_idx[(int64_t)k * nq + j]]; },
@@ -239,11 +247,11 @@ QRLSH_EXPORT int qrlsh_predict(const int32_t *ratings, int64_t nu, int64_t nq, c
               dim3(256), 0, st, q_off, q_idx, q_val, nq, (int)kq, idx_t, val_t);
     QR_LAUNCH("predict", predict_kernel<true>, dim3((unsigned)ceil_div64(nu * nq, 256)), dim3(256), 0, st, ratings, nu,
               nq, q_off, (const int32_t *)idx_t, (const double *)val_t, u_idx, u_val, ku, query_weight, user_weight,
-              default_mean, (int)(sum_order == QRLSH_SUM_SEQUENTIAL), out);
+              default_mean, (int)(sum_order == QRLSH_SUM_SEQUENTIAL), (int)kq, out);
   } else {
     QR_LAUNCH("predict", predict_kernel<false>, dim3((unsigned)ceil_div64(nu * nq, 256)), dim3(256), 0, st, ratings, nu,
               nq, q_off, q_idx, q_val, u_idx, u_val, ku, query_weight, user_weight, default_mean,
-              (int)(sum_order == QRLSH_SUM_SEQUENTIAL), out);
+              (int)(sum_order == QRLSH_SUM_SEQUENTIAL), PRED_MAXK, out);
   }
   QR_LAUNCH_CHECK("qrlsh_predict");
   return QRLSH_OK;

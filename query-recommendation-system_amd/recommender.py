@@ -14,7 +14,7 @@ reference's is arbitrary.
 
 Widening beyond the hot path: answer sets (compute_shingles, N2) and the
 hybrid prediction loop (compute_scores / weighted_average, N1) run on the device; CSV ingest
-(init / parse_queries, N3) uses pandas instead of datatable; user similarity (N4) is the same
+(init / parse_queries, N3) takes datatable Frames (what main.py passes) or pandas frames; user similarity (N4) is the same
 sklearn pipeline the reference calls, on the host.
 """
 import math
@@ -38,6 +38,21 @@ DEFAULT_MEAN = 60
 LSH_THRESH = 0.2  # recommender.py:153
 
 
+def _as_pandas(x):
+    """pandas view of a frame-like argument of init(): a pandas DataFrame as is, a datatable Frame (or any object
+    with .to_pandas()) through its own conversion, anything else through numpy"""
+    if isinstance(x, pd.DataFrame):
+        return x
+    if hasattr(x, "to_pandas"):
+        return x.to_pandas()
+    names = getattr(x, "names", None)
+    return pd.DataFrame(np.asarray(x), columns=list(names) if names is not None else None)
+
+
+def _as_numpy(x):
+    return x.to_numpy() if hasattr(x, "to_numpy") else np.asarray(x)
+
+
 class Recommender:
 
     device = "cuda"
@@ -49,20 +64,25 @@ class Recommender:
         if self.verbose:
             print(*a)
 
+    sum_order = "sequential"   # order of weighted_average's two np.sum calls, see compute_scores
+
     def init(self, users, queries, queriesIDs, dataset, ratings):
-        """recommender.py:51-64 for pandas inputs (N3: no datatable): users = one-column frame of
-        user ids, queries = frame from parse_queries, dataset = the table, ratings = the utility
-        matrix frame with its leading 'user' column; missing ratings become 0."""
-        def to_np(x):
-            return x.to_numpy() if hasattr(x, "to_numpy") else np.asarray(x)
-        self.usersIDs = to_np(users).T[0]
-        self.queries = to_np(queries)
+        """recommender.py:51-64.  Takes what main.py:23-85 passes -- `datatable` Frames (anything Frame-like:
+        `.to_pandas()` / `.to_numpy()` / `.names`) -- and pandas frames / arrays alike (N3): users = one column
+        of user ids, queries = the frame parse_queries returned, dataset = the table (every column becomes
+        str, :57), ratings = the utility matrix with its leading 'user' column (dropped, :61; missing ratings
+        become 0, :62).  The caller's frames are not modified (the reference edits `dataset` and `ratings` in
+        place; nothing reads them afterwards)."""
+        self.usersIDs = _as_numpy(users).T[0]
+        self.queries = _as_numpy(queries)
         self.queriesIDs = np.array(queriesIDs)
-        self.dataset = dataset.astype(str)
+        self.dataset = _as_pandas(dataset).astype(str)
         self.tupleCount = {}
-        if hasattr(ratings, "columns") and "user" in ratings.columns:
-            ratings = ratings.drop(columns=["user"])
-        self.ratings = np.nan_to_num(to_np(ratings).astype(np.float64), nan=0.0).astype(np.int64)
+        r = _as_pandas(ratings)
+        if "user" in list(r.columns):
+            r = r.drop(columns=["user"])
+        r = r.apply(pd.to_numeric, errors="coerce") if any(dt == object for dt in r.dtypes) else r
+        self.ratings = np.nan_to_num(r.to_numpy(dtype=np.float64, na_value=np.nan), nan=0.0).astype(np.int64)
 
     def parse_queries(self, path: str):
         """recommender.py:386-416: one query per line, `id,attr=value,attr=value,...`;
@@ -196,8 +216,13 @@ class Recommender:
         self._log("\n========== WEIGHTED AVERAGES ==========")
         t0 = time.time()
         scores_to_predict = np.array(np.where(self.ratings == 0)).T
+        # weighted_average (recommender.py:36) is @jit(nopython=True): where the reference runs as shipped
+        # (requirements.txt: numba) its np.sum is ONE accumulator in index order -> sum_order "sequential" (default).
+        # "pairwise" is numpy's own np.sum order, what the reference does with @jit removed -- the run the committed
+        # fixtures were captured from (numba is not installable here), on which both orders give the same matrices;
+        # parity with the numba build itself stays unpinned.
         final = predict.fill_predictions(self.ratings, res.src, res.dst, res.val, user_sim, QUERY_WEIGHT, USER_WEIGHT,
-                                         DEFAULT_MEAN, self.device)
+                                         DEFAULT_MEAN, self.device, sum_order=self.sum_order)
         final = final.cpu().numpy()
         self._log(str(round(time.time() - t0, 3)) + "s for weighted averages")
         finalPredictions = pd.DataFrame(final, columns=self.queriesIDs, index=self.usersIDs).astype(int)

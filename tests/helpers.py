@@ -108,3 +108,52 @@ def generator_table_and_queries(sub):
                 el[feats.index(a[0])] = a[1]
             qrows.append(el)
     return [dataset[f].to_numpy() for f in feats], np.array(qrows, dtype=object)
+
+
+# ---------------------------------------------------------------------------- N3: what main.py hands to init()
+class FrameStandIn:
+    """A pandas-backed stand-in for the `datatable.Frame` objects main.py:23-85 builds (datatable is not
+    installable here): exactly the read-only surface a Frame offers to a consumer -- .names, .shape,
+    .to_numpy(), .to_pandas() -- and nothing of pandas' own (no .columns, .astype, .drop), so a drop-in init()
+    that only duck-types pandas fails on it the way it would on a real Frame."""
+
+    def __init__(self, df):
+        self._df = df
+
+    @property
+    def names(self):
+        return tuple(str(c) for c in self._df.columns)
+
+    @property
+    def shape(self):
+        return self._df.shape
+
+    def to_numpy(self):
+        return self._df.to_numpy()
+
+    def to_pandas(self):
+        return self._df.copy()
+
+
+def fread_like(path, header=True, columns=None):
+    """dt.fread(path[, header=False][, columns=[...]]) as main.py uses it, on pandas: the utility matrix's
+    header names only the query columns while every row leads with the user id, so fread sees one column more
+    than names and main.py:70-77 passes the full list (["user"] + queriesIDs)."""
+    import pandas as pd
+    if not header:
+        return FrameStandIn(pd.read_csv(path, header=None))
+    if columns is not None:
+        return FrameStandIn(pd.read_csv(path, header=None, skiprows=1, names=list(columns)))
+    return FrameStandIn(pd.read_csv(path))
+
+
+def main_py_inputs(rec, gdir):
+    """the objects main.py builds before recommender.init (same order, same calls on `rec`):
+    -> (users, queries, queriesIDs, dataset, ratings)"""
+    dataset = fread_like(os.path.join(gdir, "dataset.csv"))                       # main.py:23
+    rec.datasetFeatures = list(dataset.names)[1::]                                # main.py:33
+    users = fread_like(os.path.join(gdir, "users.csv"), header=False)             # main.py:42
+    queries, qids = rec.parse_queries(os.path.join(gdir, "queries.csv"))          # main.py:59
+    cols = ["user"] + qids                                                        # main.py:70
+    ratings = fread_like(os.path.join(gdir, "utility_matrix.csv"), columns=cols)  # main.py:77
+    return users, queries, qids, dataset, ratings

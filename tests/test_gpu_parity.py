@@ -1011,6 +1011,69 @@ def test_compute_scores_dropin_matches_reference_on_generator_default_inputs(sub
     rec.top_k_queries(to_predict, final, missed, ask=lambda prompt: next(answers))
 
 
+@pytest.mark.parametrize("sub", GENERATOR_SETS)
+def test_main_py_call_order_with_frame_inputs_reaches_golden_final(sub):
+    """N3: main.py unchanged as the caller -- its call order (main.py:23-93) with Frame-like inputs (the
+    datatable-Frame stand-in of tests/helpers.py: no pandas surface) through init -> compute_scores gives the
+    reference's finalPredictions, for both orders of weighted_average's sums (the fixtures hold no cell on
+    which they differ; the drop-in defaults to numba's sequential order)."""
+    import recommender as R
+    from helpers import main_py_inputs
+    g = load(sub + "_scores")
+    for order in ("sequential", "pairwise"):
+        rec = R.Recommender()
+        rec.verbose = False
+        assert rec.sum_order == "sequential"
+        rec.sum_order = order
+        users, queries, qids, dataset, ratings = main_py_inputs(rec, os.path.join(GOLDEN, sub))
+        rec.init(users, queries, qids, dataset, ratings)
+        R.PERM = int(g["P"])
+        np.random.seed(int(g["seed"]))
+        to_predict, final, missed = rec.compute_scores()
+        assert list(final.columns) == qids and list(final.index) == users.to_numpy().T[0].tolist()
+        assert np.array_equal(final.to_numpy(), g["final"])
+        assert np.array_equal(to_predict, g["to_predict"]) and np.array_equal(missed, g["missed"])
+        csv_rows = final.to_numpy().tolist()            # main.py:103-107 (export) works on the returned frame
+        csv_rows[0].insert(0, final.index.values[0])
+        assert len(csv_rows[0]) == len(qids) + 1
+    R.PERM = 180
+
+
+def test_predict_c_entry_flags_a_too_long_list_without_walking_it():
+    """qrlsh_predict called directly with kq below the real longest list (and a CSR list beyond 64)
+    raises *too_long_out and never reads past the transposed workspace: the cells of such a query get 0."""
+    import ctypes
+    from qrlsh import _lib
+    lib = _lib.load()
+    nu, nq = 3, 300
+    rng = np.random.RandomState(5)
+    ratings = rng.randint(0, 5, size=(nu, nq)).astype(np.int32)
+    deg = np.full(nq, 4, dtype=np.int64)
+    deg[7] = 9          # longer than the kq the caller states
+    deg[11] = 70        # longer than PRED_MAXK
+    q_off = np.concatenate(([0], np.cumsum(deg))).astype(np.int64)
+    q_idx = rng.randint(0, nq, size=int(q_off[-1])).astype(np.int32)
+    q_val = np.round(rng.rand(int(q_off[-1])), 3)
+    u_idx = np.full((nu, 1), -1, dtype=np.int32)
+    u_val = np.zeros((nu, 1))
+    d = [dev(x) for x in (ratings, q_off, q_idx, q_val, u_idx, u_val)]
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    for kq in (4, 0):
+        out = torch.full((nu, nq), -7, dtype=torch.int32, device=DEV)
+        flag = torch.zeros((1,), dtype=torch.int32, device=DEV)
+        ws = torch.zeros((max(16, int(lib.qrlsh_predict_workspace_bytes(nq, kq))),), dtype=torch.uint8, device=DEV)
+        rc = lib.qrlsh_predict(vp(d[0]), nu, nq, vp(d[1]), vp(d[2]), vp(d[3]), vp(d[4]), vp(d[5]), 0, 0.6, 0.4, 60.0,
+                               _lib.SUM_PAIRWISE, vp(out), vp(flag), kq, vp(ws) if kq else None, ws.numel(), None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert int(flag.item()) == 1
+        o = out.cpu().numpy()
+        bad = [11] if kq == 0 else [7, 11]
+        for j in bad:
+            assert np.array_equal(o[:, j], np.where(ratings[:, j] != 0, ratings[:, j], 0))
+        assert (o != -7).all()
+
+
 def _check_user_sims_tie_aware(mine, ref, K):
     """mine / ref: {u: {'indexes', 'values'}}.  The reference keeps zero-valued entries (the user itself, negative
     cosines) when a cluster has fewer than K positive neighbours and orders ties arbitrarily (np.argsort); the

@@ -146,3 +146,30 @@ def test_generator_write_csv_shim(tmp_path, monkeypatch):
     generator.write_csv("noheader", None, [[1, 2]])
     assert open(tmp_path / "output" / "final_predictions.csv").read().splitlines() == ["Q1,Q2", "U1,3,4", "U2,0,7"]
     assert open(tmp_path / "output" / "noheader.csv").read().splitlines() == ["1,2"]
+
+
+@pytest.mark.parametrize("sub", ["cfg1", "cfg1b", "cfg2"])
+def test_init_accepts_what_main_py_passes(sub):
+    """N3: main.py:23-85 hands datatable Frames to Recommender.init (recommender.py:51-64).  A Frame-like stand-in
+    (tests/helpers.py: .names / .shape / .to_numpy() / .to_pandas() only) and plain pandas frames must give the
+    same state, equal to what the reference's own init leaves behind (the golden `ratings`)."""
+    import pandas as pd
+    import recommender as R
+    from helpers import GOLDEN, load, main_py_inputs
+    g = load(sub + "_scores")
+    gdir = os.path.join(GOLDEN, sub)
+    rec = R.Recommender()
+    users, queries, qids, dataset, ratings = main_py_inputs(rec, gdir)
+    assert not hasattr(dataset, "columns") and not hasattr(ratings, "astype")   # really not pandas
+    rec.init(users, queries, qids, dataset, ratings)
+    assert np.array_equal(rec.ratings, g["ratings"]) and rec.ratings.dtype == np.int64
+    assert rec.usersIDs.tolist() == pd.read_csv(os.path.join(gdir, "users.csv"), header=None)[0].tolist()
+    assert list(rec.queriesIDs) == qids and rec.queries.shape == (len(qids), len(rec.datasetFeatures))
+    assert all(isinstance(v, str) for v in rec.dataset.iloc[0].tolist())          # dataset[:] = dt.str64
+    assert rec.dataset["age"].iloc[0] == str(pd.read_csv(os.path.join(gdir, "dataset.csv"))["age"].iloc[0])
+    # the same through pandas frames
+    rec2 = R.Recommender()
+    rec2.datasetFeatures = rec.datasetFeatures
+    rec2.init(users.to_pandas(), queries, qids, dataset.to_pandas(), ratings.to_pandas())
+    assert np.array_equal(rec2.ratings, rec.ratings) and rec2.dataset.equals(rec.dataset)
+    assert np.array_equal(rec2.usersIDs, rec.usersIDs) and np.array_equal(rec2.queries, rec.queries)
