@@ -453,9 +453,11 @@ def test_synth_generator_matches_oracle_twin():
 
 @pytest.mark.parametrize("nq,D,P,b", [(20000, 32768, 128, 32), (30000, 100000, 128, 32), (12000, 32768, 256, 64),
                                       (200000, 32768, 128, 32), (25000, 32768, 100, 20), (9000, 70000, 96, 12),
-                                      (30000, 50000, 128, 32)])   # compact rows whose values pass 2^15: no dot2 form
+                                      (30000, 50000, 128, 32),    # compact rows whose values pass 2^15: no dot2 form
+                                      (1_000_000, 100000, 128, 32)])   # SURVEY 8d's parity-only run: int32 table and rows, int16 wrap in the keys
 def test_pipeline_equals_oracle_on_synthetic(nq, D, P, b):
     K = pipeline.max_candidates(nq)
+    O.set_threads(16)
     off, rows = qrlsh.synth_csr(nq, D, seed=0, device=DEV)
     perms = ops.legacy_permutations(P, D, seed=42)
     res = pipeline.query_similarities(off, rows, ops.perm_table(perms, DEV), b, K)
@@ -631,11 +633,33 @@ def _run_dist_gpu(tmp_path, world, nq, D, P, b, mode, backend, port, sig_mode="a
     env["OMP_NUM_THREADS"] = "1"
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     env.update(env_extra or {})
-    cmd = [_sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "tests", "dist_gpu_worker.py"),
-           str(tmp_path), str(nq), str(D), str(P), str(b), mode, backend, sig_mode, str(mean)]
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
-    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    # the ranks are started directly (env-variable rendezvous), not through torch.distributed.run: its agent
+    # process counts against the 6 processes a GPU box admits on its card (this process + at most 5 ranks)
+    args = [_sys.executable, os.path.join(root, "tests", "dist_gpu_worker.py"),
+            str(tmp_path), str(nq), str(D), str(P), str(b), mode, backend, sig_mode, str(mean)]
+    procs, logs = [], []
+    for rk in range(world):
+        e = dict(env, RANK=str(rk), LOCAL_RANK=str(rk), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                 MASTER_PORT=str(port))
+        logs.append(open(os.path.join(str(tmp_path), "rank%d.log" % rk), "w+"))
+        procs.append(subprocess.Popen(args, env=e, stdout=logs[-1], stderr=subprocess.STDOUT))
+    failed, deadline = False, 900
+    for pr in procs:
+        try:
+            pr.wait(timeout=deadline)
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            pr.wait()
+        failed = failed or pr.returncode != 0
+        if failed:
+            deadline = 20          # a peer is gone: the others cannot finish their collectives
+    texts = []
+    for f in logs:
+        f.seek(0)
+        texts.append(f.read()[-3000:])
+        f.close()
+    assert not failed, "\n".join("--- rank %d (rc %s)\n%s" % (k, pr.returncode, t)
+                                  for k, (pr, t) in enumerate(zip(procs, texts)))
     return [np.load(os.path.join(tmp_path, "rank%d.npz" % r)) for r in range(world)]
 
 
@@ -709,6 +733,127 @@ def test_sharded_config3_shape_four_ranks(tmp_path):
     _check_sharded_against(outs, res, nq, world)
     sizes = [len(o["pairs"]) for o in outs]
     assert max(sizes) < 1.05 * sum(sizes) / world                # the scoring work is split evenly
+
+
+def test_sharded_config3_shape_five_ranks_all_gather_of_bucket_ids(tmp_path):
+    """configs[3] with the exchange BASELINE's north_star names -- an ALL-GATHER of the bucket ids -- and the row
+    fetch ("fetch": what `auto` picks for the 8-GPU run), at the largest rank count this box allows: a GPU box admits
+    at most 6 processes on its card: five ranks + this process (the 8-rank layout -- 4 bands per rank, shards of
+    1.25 M -- is covered on the CPU by tests/test_dist_cpu.py at world 8 and, rank by rank at configs[4]'s size, by
+    test_config4_rank_slice below).  32 bands over 5 ranks is an UNEVEN band split (7, 7, 7, 7, 4)."""
+    nq, D, P, b, world = 10_000_000, 32768, 128, 32, 5
+    outs = _run_dist_gpu(tmp_path, world, nq, D, P, b, "all_gather", "gloo", 29631, "fetch")
+    K = pipeline.max_candidates(nq)
+    off, rows = qrlsh.synth_csr(nq, D, seed=0, device=DEV)
+    res = pipeline.query_similarities(off, rows, ops.perm_table(ops.legacy_permutations(P, D, seed=42), DEV), b, K)
+    torch.cuda.synchronize()
+    _check_sharded_against(outs, res, nq, world)
+    sizes = [len(o["pairs"]) for o in outs]
+    assert max(sizes) < 1.05 * sum(sizes) / world
+    for o in outs:
+        assert str(o["sig_exchange"]) == "fetch"
+    del res
+    torch.cuda.empty_cache()
+
+
+def test_config4_rank_slice():
+    """BASELINE configs[4] (100 M queries x 256-perm MinHash, 64 bands, 8 ranks) as ONE rank of the eight sees it,
+    at its own size: rank 0's 12.5 M local signatures at P = 256, the keys of its 8 owned bands over all 100 M
+    ids in the [rank][band][queries] layout the band-partitioned all-to-all delivers (6.4 GB, read in place by
+    the partition: T = 15, two steps, 27-bit ids), pair emission, hosting split, region de-duplication at 27 id
+    bits, remote-row fetch and split-table scoring -- the calls qrlsh.dist makes between its collectives, with the
+    other ranks' contributions (their keys, their rows) computed here.  Checked exactly against the oracle where
+    the host allows: every candidate pair of the owned bands (oracle bucketing of 8 x 100 M keys), this rank's
+    share of them, the scores of a 2 M-pair sample; and through properties for the rest."""
+    from qrlsh import dist as qdist
+    from dist_worker import pair_host
+    nq, D, P, b, world, rank = 100_000_000, 32768, 256, 64, 8, 0
+    r = P // b
+    q0, n_real, nql = qdist.shard_range(nq, world, rank)
+    lo, hi = qdist.band_owner_ranges(b, world)[rank]
+    nb = hi - lo
+    assert (nql, nb, n_real) == (12_500_000, 8, 12_500_000)
+    perms = ops.legacy_permutations(P, D, seed=42)
+    table = ops.perm_table(perms, DEV)
+    recv = torch.empty((world, nb, nql), dtype=torch.int64, device=DEV)
+    sig_all = torch.empty((nq, P), dtype=torch.int16, device=DEV)            # 51 GB: every rank's rows (288 GB HBM)
+    norm_all = torch.empty((nq,), dtype=torch.int64, device=DEV)
+    keys = torch.empty((b, nql), dtype=torch.int64, device=DEV)
+    O.set_threads(16)
+    for s_ in range(world):
+        off, rows = qrlsh.synth_csr(nq, D, seed=0, q0=s_ * nql, nq_local=nql, device=DEV)
+        blk = slice(s_ * nql, (s_ + 1) * nql)
+        ops.minhash(off, rows, table, b=b, compact=True, validate=(s_ == rank), out=(sig_all[blk], norm_all[blk], keys))
+        recv[s_].copy_(keys[lo:hi])
+        if s_ in (0, world - 1):        # the first 100 000 signatures of the first / last shard against the oracle
+            n_chk = 100_000
+            ho = off[: n_chk + 1].cpu().numpy()
+            osig = O.minhash(ho, rows[: int(ho[-1])].cpu().numpy(), perms)
+            assert np.array_equal(ops.sig_to_int32(sig_all[s_ * nql: s_ * nql + n_chk]).cpu().numpy(), osig)
+            assert np.array_equal(keys[:, :n_chk].cpu().numpy().view(np.uint64), O.band_keys(osig, b).T)
+        del off, rows
+    del keys
+    # 3. pairs of the owned bands over all ids, from the exchanged layout in place
+    #    (the product call: the partition + LDS finish, or -- when a part overflows its LDS image -- the general sort path)
+    be = qdist.HipBackend()
+    emitted = be.emit_pairs_chunked(recv.view(-1), world, nb, nql, r)
+    assert ops.part_bits_for(nq) == 15
+    bucket_path = be.stats["bucket_path"]
+    n_emitted = emitted.numel()
+    # 4. hosting split: what this rank keeps of its own emission
+    grouped, _ = ops.sort_u64(emitted, None, host_shard=nql)
+    del emitted
+    bounds = ops.owner_bounds(grouped, -1, nql, world).tolist()
+    shares = np.diff(bounds)
+    assert shares.sum() == n_emitted and shares.max() < 1.05 * shares.mean()   # the coin splits evenly
+    mine = grouped[bounds[rank]:bounds[rank + 1]].clone()
+    del grouped
+    stats = {}
+    pairs = ops.unique_pairs(mine, nq, stats, words_per_query=mine.numel() / (2 * nql))
+    del mine
+    assert stats["dedup_path"] == "regions-in-lds" and stats["group_bits"] == 5
+    hp = u64(pairs)
+    assert np.all(hp[1:] > hp[:-1])
+    i, j = (hp >> np.uint64(32)).astype(np.int64), (hp & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    assert np.all(i < j) and j.max() < nq and np.all(pair_host(hp, nql) == rank)
+    # oracle: the owned bands' buckets over all 100 M ids
+    kq = recv.permute(0, 2, 1).reshape(nq, nb).contiguous().cpu().numpy().view(np.uint64)   # query-major [q][band]
+    assert O.emitted_pairs(kq[:1_000_000], r) >= 0
+    opairs = O.candidates(kq, r)
+    del kq
+    assert np.array_equal(hp, opairs[pair_host(opairs, nql) == rank])
+    del opairs
+    # 5. the rows the pairs need: ids requested from their owners (here: gathered out of the full table)
+    rid = ops.remote_ids(pairs, q0, nql, nq, world)
+    sizes = rid.bounds.tolist()
+    need = ops.remote_id_list(rid, sizes[-1])
+    hn = need.cpu().numpy()
+    assert np.all(hn[1:] > hn[:-1]) and np.all((hn < q0) | (hn >= q0 + nql))
+    touched = np.unique(np.concatenate([i, j]))
+    assert np.array_equal(hn, touched[(touched < q0) | (touched >= q0 + nql)])
+    rows_b, norms_b = ops.gather_rows(sig_all, norm_all, need, 0)
+    local = ops.remap_pairs_ids(pairs, rid)
+    milli = ops.score_pairs_split(sig_all[q0:q0 + nql], norm_all[q0:q0 + nql], rows_b, norms_b, local)
+    whole, _, _ = ops.score_pairs(sig_all, norm_all, pairs)            # the same pairs against the one-piece table
+    assert torch.equal(milli, whole)
+    del whole, rows_b, norms_b, local
+    # oracle scores on a sample of 2 M pairs (their rows re-indexed into a small table)
+    step = max(1, len(hp) // 2_000_000)
+    sp = hp[::step]
+    si, sj = (sp >> np.uint64(32)).astype(np.int64), (sp & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    ids = np.unique(np.concatenate([si, sj]))
+    small = ops.sig_to_int32(sig_all[torch.from_numpy(ids).to(DEV)]).cpu().numpy()
+    rp = (np.searchsorted(ids, si).astype(np.uint64) << np.uint64(32)) | np.searchsorted(ids, sj).astype(np.uint64)
+    assert np.array_equal(milli.cpu().numpy()[::step], O.score_pairs(small, rp, mode=1))
+    # 6. both directed edges of every scored pair, ready for the owner exchange
+    ib = ops.id_bits_for(nq)
+    assert ib == 27 and ops.wide_ids(ib)
+    ek, ed = ops.pair_edges_interleaved(pairs, milli, ib, wide=True)
+    assert ek.numel() == 2 * pairs.numel() and ed.numel() == 2 * pairs.numel()
+    print("configs[4] rank slice: bucket path %s, emitted %d, hosted here %d unique, remote rows %d"
+          % (bucket_path, n_emitted, len(hp), len(hn)))
+    del sig_all, norm_all, recv
+    torch.cuda.empty_cache()
 
 
 def test_sharded_driver_wide_ids_beyond_2_pow_26(tmp_path):
