@@ -415,6 +415,12 @@ int qrlsh_synth_fill(uint64_t seed, int64_t q0, int64_t nq_local, int64_t nq_tot
  * bench.py uses this for the live roofline figures.
  */
 int qrlsh_prof_enable(int on);
+/* Intra-call overlap: qrlsh_bucket_pairs_emit* works its bands in groups that alternate between the caller's stream
+ * and one auxiliary stream of the library (forked from / joined back into the caller's stream inside the call, so
+ * the call stays ONE asynchronous operation on `stream`), letting a group's LDS-bound finish share the device
+ * with the next group's memory-bound partition.  On by default; 0 (or the environment variable QRLSH_OVERLAP=0,
+ * read on first use) runs everything on the caller's stream.  Steps bracketed by the profiler run serially. */
+int qrlsh_set_overlap(int on);
 int qrlsh_prof_pause(int paused);
 int qrlsh_prof_report(char *buf_host, size_t buflen);
 

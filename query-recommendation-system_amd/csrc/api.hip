@@ -1,6 +1,7 @@
 // api.hip -- library-wide plumbing of libqrlsh: version, thread-local error text, and an
 // optional per-kernel profiler built on HIP events recorded on the launch stream.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -58,6 +59,60 @@ void qr_prof_end(int slot, hipStream_t st) {
   if (slot < 0) return;
   std::lock_guard<std::mutex> lk(g_mu);
   if (slot < (int)g_recs.size()) (void)hipEventRecord(g_recs[slot].b, st);
+}
+
+bool qr_prof_active() {
+  std::lock_guard<std::mutex> lk(g_mu);
+  return g_on;
+}
+
+// ---- auxiliary stream for intra-call overlap ------------------------------------------------
+// A few entry points run independent pieces of their work (band groups of the bucket path) on a second stream
+// beside the caller's, so that a latency-bound kernel of one piece shares the device with a bandwidth-bound
+// kernel of the next.  Fork: the auxiliary stream waits for everything already queued on the caller's
+// stream; join: the caller's stream waits for the auxiliary one -- to the caller the entry point is still one
+// asynchronous call on its stream.  One auxiliary stream and two events per device, created on first use.
+namespace {
+struct Aux { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool ok = false, tried = false; };
+Aux g_aux[16];
+int g_overlap = -1;  // -1: read QRLSH_OVERLAP on first use (default on)
+}  // namespace
+
+QRLSH_EXPORT int qrlsh_set_overlap(int on) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_overlap = on != 0;
+  return QRLSH_OK;
+}
+
+hipStream_t qr_aux_fork(hipStream_t st) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (g_overlap < 0) {
+    const char *e = getenv("QRLSH_OVERLAP");
+    g_overlap = !(e && e[0] == '0');
+  }
+  if (!g_overlap || g_on) return nullptr;  // (profiled steps run serially: per-kernel times stay per-kernel)
+  Aux &a = g_aux[dev];
+  if (!a.tried) {
+    a.tried = true;
+    a.ok = hipStreamCreateWithFlags(&a.s, hipStreamNonBlocking) == hipSuccess &&
+           hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&a.join, hipEventDisableTiming) == hipSuccess;
+  }
+  if (!a.ok) return nullptr;
+  if (hipEventRecord(a.fork, st) != hipSuccess || hipStreamWaitEvent(a.s, a.fork, 0) != hipSuccess) return nullptr;
+  return a.s;
+}
+
+void qr_aux_join(hipStream_t st) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  Aux &a = g_aux[dev];
+  if (!a.ok) return;
+  (void)hipEventRecord(a.join, a.s);
+  (void)hipStreamWaitEvent(st, a.join, 0);
 }
 
 QRLSH_EXPORT int qrlsh_prof_enable(int on) {

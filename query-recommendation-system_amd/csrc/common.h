@@ -33,6 +33,10 @@ void qrlsh_set_error(const char *fmt, ...);
 int qr_prof_begin(const char *label, hipStream_t st);
 void qr_prof_end(int slot, hipStream_t st);
 
+// second stream for overlapping independent pieces of one call (api.hip); nullptr = run everything on `st`
+hipStream_t qr_aux_fork(hipStream_t st);
+void qr_aux_join(hipStream_t st);
+
 #define QR_LAUNCH(label, kern, grid, block, smem, st, ...)               \
   do {                                                                   \
     const int ps__ = qr_prof_begin(label, st);                           \

@@ -1180,50 +1180,65 @@ QRLSH_EXPORT int qrlsh_bucket_pairs_emit_chunked(const uint64_t *keys, int64_t k
   // the atomic partition hands the finish x = mix64(key): its free-slot marker is mix64(empty key)
   const uint64_t ekx = qr_mix64(qr_empty_key(r));
 #define QR_PART_SCATTER(LEVEL2_, ...) QR_LAUNCH("part_scatter", (part_scatter_atomic_kernel<LEVEL2_>), __VA_ARGS__)
-  if (part_bits == 8 && one_kernel_partition(nq, part_bits)) {
-    // one-kernel partition into fixed regions; the part cursors live where the general path keeps `starts`
-    const uint32_t cap = part_region(nq);
-    uint32_t *cursors = w.starts;
-    if (hipMemsetAsync(cursors, 0, (size_t)b * RADIX * sizeof(uint32_t), st) != hipSuccess) {
-      qrlsh_set_error("qrlsh_bucket_pairs_emit: hipMemsetAsync failed");
-      return QRLSH_EHIP;
-    }
-    const int ntiles = (int)ceil_div64(nq, PS_TILE);
-    QR_PART_SCATTER(false, dim3(ntiles, b), dim3(SORT_THREADS), 0, st, keys, (const uint32_t *)nullptr, part_keys,
-                    part_ids, nq, ntiles, 56, (uint32_t)RADIX - 1u, cursors, cap,
-                    reinterpret_cast<uint32_t *>(total_overflow_out + 1), qr_empty_key(r), (const uint32_t *)nullptr, 0u,
-                    key_chunk, key_chunk_stride, key_band_stride);
-    QR_LAUNCH("bucket_emit", (bucket_finish_kernel<FIN_EMIT>), dim3(nparts, b), dim3(FIN_THREADS), 0, st,
-              (const uint64_t *)part_keys, (const uint32_t *)part_ids, nq, (const uint32_t *)nullptr, nparts,
-              ekx, total_overflow_out, reinterpret_cast<uint32_t *>(total_overflow_out + 1), pairs_out,
-              capacity, (const uint32_t *)cursors, cap);
-    QR_LAUNCH_CHECK("qrlsh_bucket_pairs_emit");
-    return QRLSH_OK;
-  }
   if (one_kernel_partition(nq, part_bits)) {
-    // two steps of the same kernel: 2^c1 coarse regions per band into the tmp buffers, then every coarse
-    // region into its 2^(T-c1) fine regions; cursors of step 1 borrow the histogram area, step 2's `starts`
+    // One-kernel partition(s) into fixed regions + the LDS finish.  The bands are independent of each other all the
+    // way to the pair cursor, so they are worked in GROUPS that alternate between the caller's stream and an
+    // auxiliary one (api.hip: qr_aux_fork): while one group sits in the finish -- a chain of LDS phases that
+    // leaves most of the memory system idle -- the next group's partition, which is nothing but memory traffic,
+    // shares the device with it.  Same kernels, same buffers (every group touches only its own bands' regions,
+    // cursors and counts), results as unordered as before; QRLSH_OVERLAP=0 (or an active profiler) runs the
+    // groups one after the other on the caller's stream.
     const int T = part_bits;
-    const int c1 = coarse_bits(T);
-    const uint32_t cap1 = coarse_region(nq, c1), cap2 = fine_region(nq, T), lowmask = (1u << (T - c1)) - 1u;
-    uint32_t *cur1 = w.ghist, *cur2 = w.starts;
+    const bool two = T > 8;
+    const int c1 = two ? coarse_bits(T) : 8;
+    const uint32_t cap1 = two ? coarse_region(nq, c1) : part_region(nq), cap2 = two ? fine_region(nq, T) : cap1;
+    const uint32_t lowmask = (1u << (T - c1)) - 1u;
+    // step-1 cursors: the histogram area (two steps) or `starts` (one step, read by the finish); step-2: `starts`
+    uint32_t *cur1 = two ? w.ghist : w.starts, *cur2 = w.starts;
     if (hipMemsetAsync(cur1, 0, ((size_t)b << c1) * sizeof(uint32_t), st) != hipSuccess ||
-        hipMemsetAsync(cur2, 0, ((size_t)b << T) * sizeof(uint32_t), st) != hipSuccess) {
+        (two && hipMemsetAsync(cur2, 0, ((size_t)b << T) * sizeof(uint32_t), st) != hipSuccess)) {
       qrlsh_set_error("qrlsh_bucket_pairs_emit: hipMemsetAsync failed");
       return QRLSH_EHIP;
     }
     uint32_t *ovf = reinterpret_cast<uint32_t *>(total_overflow_out + 1);
     const int ntiles = (int)ceil_div64(nq, PS_TILE);
-    QR_PART_SCATTER(false, dim3(ntiles, b), dim3(SORT_THREADS), 0, st, keys, (const uint32_t *)nullptr, tmp_keys,
-                    tmp_ids, nq, ntiles, 64 - c1, (1u << c1) - 1u, cur1, cap1, ovf, qr_empty_key(r),
-                    (const uint32_t *)nullptr, 0u, key_chunk, key_chunk_stride, key_band_stride);
-    QR_PART_SCATTER(true, dim3((unsigned)ceil_div64(cap1, PS_TILE), b << c1), dim3(SORT_THREADS), 0, st,
-                    (const uint64_t *)tmp_keys, (const uint32_t *)tmp_ids, part_keys, part_ids, (int64_t)0, 0, 64 - T,
-                    lowmask, cur2, cap2, ovf, qr_empty_key(r), (const uint32_t *)cur1, cap1, (int64_t)0, (int64_t)0,
-                    (int64_t)0);
-    QR_LAUNCH("bucket_emit", (bucket_finish_kernel<FIN_EMIT>), dim3(nparts, b), dim3(FIN_THREADS), 0, st,
-              (const uint64_t *)part_keys, (const uint32_t *)part_ids, nq, (const uint32_t *)nullptr, nparts,
-              ekx, total_overflow_out, ovf, pairs_out, capacity, (const uint32_t *)cur2, cap2);
+    const int64_t band_words = key_band_stride ? key_band_stride : nq;  // words between two bands of the key matrix
+    static int groups_env = -1;
+    if (groups_env < 0) {
+      const char *e = getenv("QRLSH_EMIT_GROUPS");
+      groups_env = e ? atoi(e) : 2;  // 10 M queries x 32 bands: 18.84 ms per step with 1 group, 18.42 with 2, 18.9 with 4, 19.2 with 8
+      if (groups_env < 1) groups_env = 1;
+    }
+    const int GROUPS = groups_env;
+    const int per = (b + GROUPS - 1) / GROUPS;
+    hipStream_t aux = nullptr;
+    int gi = 0;
+    for (int g0 = 0; g0 < b; g0 += per, ++gi) {
+      const int nb = (b - g0 < per) ? b - g0 : per;
+      hipStream_t s = (aux && (gi & 1)) ? aux : st;
+      uint64_t *k1 = two ? tmp_keys : part_keys;
+      uint32_t *v1 = two ? tmp_ids : part_ids;
+      QR_PART_SCATTER(false, dim3(ntiles, nb), dim3(SORT_THREADS), 0, s, keys + (size_t)g0 * band_words,
+                      (const uint32_t *)nullptr, k1 + ((size_t)g0 << c1) * cap1, v1 + ((size_t)g0 << c1) * cap1, nq,
+                      ntiles, 64 - c1, (1u << c1) - 1u, cur1 + ((size_t)g0 << c1), cap1, ovf, qr_empty_key(r),
+                      (const uint32_t *)nullptr, 0u, key_chunk, key_chunk_stride, key_band_stride);
+      if (two)
+        QR_PART_SCATTER(true, dim3((unsigned)ceil_div64(cap1, PS_TILE), nb << c1), dim3(SORT_THREADS), 0, s,
+                        (const uint64_t *)tmp_keys + ((size_t)g0 << c1) * cap1,
+                        (const uint32_t *)tmp_ids + ((size_t)g0 << c1) * cap1, part_keys + ((size_t)g0 << T) * cap2,
+                        part_ids + ((size_t)g0 << T) * cap2, (int64_t)0, 0, 64 - T, lowmask, cur2 + ((size_t)g0 << T),
+                        cap2, ovf, qr_empty_key(r), (const uint32_t *)cur1 + ((size_t)g0 << c1), cap1, (int64_t)0,
+                        (int64_t)0, (int64_t)0);
+      // the auxiliary stream is forked once the first group's partition is queued and before its finish is: the
+      // second group's partition then starts beside the first group's finish, and the two streams stay half a
+      // group out of step
+      if (gi == 0 && b > per) aux = qr_aux_fork(st);
+      QR_LAUNCH("bucket_emit", (bucket_finish_kernel<FIN_EMIT>), dim3(nparts, nb), dim3(FIN_THREADS), 0, s,
+                (const uint64_t *)part_keys + ((size_t)g0 << T) * cap2, (const uint32_t *)part_ids + ((size_t)g0 << T) * cap2,
+                nq, (const uint32_t *)nullptr, nparts, ekx, total_overflow_out, ovf, pairs_out, capacity,
+                (const uint32_t *)cur2 + ((size_t)g0 << T), cap2);
+    }
+    if (aux) qr_aux_join(st);
     QR_LAUNCH_CHECK("qrlsh_bucket_pairs_emit");
     return QRLSH_OK;
   }

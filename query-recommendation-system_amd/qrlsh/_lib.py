@@ -92,6 +92,7 @@ SIGNATURES = {
                                      ctypes.c_double, _i32, _vp, _vp, _i32, _vp, _sz, _vp]),
     "qrlsh_center_rows": (ctypes.c_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "qrlsh_prof_enable": (ctypes.c_int, [ctypes.c_int]),
+    "qrlsh_set_overlap": (ctypes.c_int, [ctypes.c_int]),
     "qrlsh_prof_pause": (ctypes.c_int, [ctypes.c_int]),
     "qrlsh_prof_report": (ctypes.c_int, [ctypes.c_char_p, _sz]),
     "qrlsh_synth_sizes": (ctypes.c_int, [_u64, _i64, _i64, _i64, _i32, _u32, _vp, _i32, _u32, _vp, _vp]),
