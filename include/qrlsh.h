@@ -367,15 +367,21 @@ int qrlsh_answer_sets_compact(const int32_t *slots, const int64_t *offsets, int6
  * plain Python; the order the committed fixtures pin), QRLSH_SUM_SEQUENTIAL = one accumulator in index
  * order (what numba's nopython np.sum does where numba is installed; unpinned here).
  * Limits: ku <= 64 (QRLSH_EINVAL otherwise); a query with more than 64 neighbours sets *too_long_out
- * (device uint32, required) to 1 and its column is not to be trusted -- the caller reads the flag back.
- * kq > 0 with a workspace of qrlsh_predict_workspace_bytes(nq, kq): the caller states the longest query list
- * (kq <= 64; a longer one sets the flag) and the lists are first transposed to [kq][nq] there, so that the
- * sweep over the cells reads them with consecutive lanes (21.7 against 32.1 ms on the bench shape); kq = 0 /
- * workspace = NULL: the lists are read in their CSR form.  Same results either way.
+ * (device uint32, required) to 1; its cells are never walked (they get 0) and the result is not to be used -- the
+ * caller reads the flag back.
+ * kq > 0 with a workspace of qrlsh_predict_workspace_bytes(nu, nq, kq): the caller states the longest query list
+ * (kq <= 64; a longer one sets the flag, as above) and the kernel that fits the data runs, same results from all:
+ *   tile form (ku <= 32, every rating in 0 .. 255 -- the reference's are 0 .. 100): the matrix is transposed to
+ *     bytes in the workspace, a workgroup owns 64 users x 16 queries, every list is read once per tile and the
+ *     rating gathers are 64 consecutive bytes (query side) or stay inside one nu-byte row (user side);
+ *   row form (nq <= 131072; what runs when a rating does not fit a byte -- decided on the device, no read-back):
+ *     one workgroup per user slice, the lists transposed to [kq][nq] in the workspace, the user's row in LDS;
+ *   cell form otherwise: one thread per cell over the transposed lists.
+ * kq = 0 / workspace = NULL: one thread per cell over the lists in their CSR form.
  */
 #define QRLSH_SUM_PAIRWISE 0
 #define QRLSH_SUM_SEQUENTIAL 1
-size_t qrlsh_predict_workspace_bytes(int64_t nq, int32_t kq);
+size_t qrlsh_predict_workspace_bytes(int64_t nu, int64_t nq, int32_t kq);
 int qrlsh_predict(const int32_t *ratings, int64_t nu, int64_t nq, const int64_t *q_off,
                   const int32_t *q_idx, const double *q_val, const int32_t *u_idx, const double *u_val,
                   int32_t ku, double query_weight, double user_weight, double default_mean,

@@ -87,7 +87,7 @@ SIGNATURES = {
     "qrlsh_answer_sets_fill": (ctypes.c_int, [_vp, _i64, _i64, _vp, _i64, _i32, _vp, _vp, _vp]),
     "qrlsh_answer_sets_sweep": (ctypes.c_int, [_vp, _i64, _i64, _vp, _i64, _i32, _vp, _vp, _vp]),
     "qrlsh_answer_sets_compact": (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),
-    "qrlsh_predict_workspace_bytes": (_sz, [_i64, _i32]),
+    "qrlsh_predict_workspace_bytes": (_sz, [_i64, _i64, _i32]),
     "qrlsh_predict": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i32, ctypes.c_double, ctypes.c_double,
                                      ctypes.c_double, _i32, _vp, _vp, _i32, _vp, _sz, _vp]),
     "qrlsh_center_rows": (ctypes.c_int, [_vp, _i64, _i64, _i64, _vp, _vp]),

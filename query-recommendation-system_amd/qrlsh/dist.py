@@ -4,6 +4,8 @@ over xGMI on the GPU box, "gloo" in the CPU tests).
 Rank g owns the contiguous query range [g*nql, (g+1)*nql), nql = ceil(nq_total / W) (the last shards are
 padded with empty answer sets, which are never candidates), and bands {k : k // ceil(b/W) == g}.
 
+With `sig_exchange` = "fetch" or "all_gather" (shards stay shards):
+
   1. MinHash + band keys + norms on the local shard (no communication).
   2. bucket-id exchange so that cross-shard candidates are found.  Two modes with identical
      results:
@@ -18,17 +20,28 @@ padded with empty answer sets, which are never candidates), and bands {k : k // 
      mean on rank 0, nothing on the last rank -- whatever the data; the coin splits evenly.  The scoring
      rank sorts + uniques what it received -> its share of the global candidate set (the shares are
      disjoint; their union is the single-GPU candidate list).
-  5. signatures for scoring.  At most one row of a pair is remote.  Two ways, identical results:
+  5. signatures for scoring.  At most one row of a pair is remote.
        "fetch" : the scoring rank asks the owners for exactly the distinct remote ids of its pairs (ids
                  out, rows + norms back);
        "all_gather": every rank receives every row ((W-1)/W * nq_total * 2P bytes per rank) on a
                  second communicator, asynchronously, beside steps 3-4.
-     "auto" (default): all_gather below 4 ranks (one or two peers: the volumes are close and the
-     gather hides behind steps 3-4), fetch from 4 ranks on.
   6. score; both directed edges of every scored pair go to the owner of their src (variable-size
      all-to-all; the local share passes through it as a device copy).
   7. per-query top-K on the edges received: re-based to the local id range, sorted on the whole
      (src, value, dst) key (edges of one query come from several scoring ranks in no useful order).
+
+With `sig_exchange` = "recompute" (answer sets replicated instead of signatures exchanged):
+
+  0. all-gather of the ANSWER SETS (row ids padded to the largest shard + the offsets, 64 + 8 bytes per
+     query) on the second communicator, beside the rank's own MinHash;
+  1. every rank computes the signatures, norms and band keys of ALL queries, its own shard first, each
+     shard's block written straight into its place of the replicated tables;
+  2. -- no bucket-id exchange: the keys of the owned bands are read in place from the replicated
+     [rank][band][queries] key buffer -- and no step 5: every row is local.  Steps 3, 4, 6, 7 as above.
+
+"auto" (default) = "recompute" for 2 to 4 ranks -- few ranks = few xGMI links, and everything a rank sends to one
+peer crosses ONE of them: 64 B of answer set per query against 256 B of signature row per scored pair plus 8 B of
+bucket id per band -- and "fetch" otherwise (one rank; five ranks and more, with seven links to spread over).
 
 Host round trips per step: the emitted-pair count, one per size exchange (pairs, row requests, edges),
 the unique-pair count and the top-K count.  Everything else is a libqrlsh kernel or a collective.

@@ -24,8 +24,9 @@ def fill_predictions(ratings, q_src, q_dst, q_milli, user_sims, query_weight=QUE
     user_sims: {u: {'indexes', 'values'}} as compute_userSimilarities returns it.
     sum_order: "pairwise" (numpy's np.sum order: the reference as plain Python, what the fixtures pin) or
     "sequential" (numba's nopython np.sum: the reference where numba is installed; unpinned).
-    transpose_lists: let the kernel sweep the query lists transposed to [longest list][nq] (coalesced; one extra
-    read-back for the longest list) instead of their CSR form; same results.
+    transpose_lists: give the library a workspace and the longest list (one extra read-back), so that it runs its
+    tile form (64 users x 16 queries per workgroup over a byte copy of the matrix) or, for ratings outside 0 .. 255,
+    its row form; False: one thread per cell over the CSR lists.  Same results.
     -> int32 device tensor (nu, nq): finalPredictions of recommender.py:301-331.
     Raises ValueError when a neighbour list is longer than 64 (K = round(log_1.5 n) stays below 52 for any
     n < 1e9; only an overridden max_candidates gets there)."""
@@ -60,7 +61,7 @@ def fill_predictions(ratings, q_src, q_dst, q_milli, user_sims, query_weight=QUE
     if kq > MAX_NEIGHBOURS:
         raise ValueError("a query has more than %d neighbours (%d; max_candidates overridden?); the prediction kernel "
                          "handles at most %d" % (MAX_NEIGHBOURS, kq, MAX_NEIGHBOURS))
-    ws = torch.empty((max(int(lib.qrlsh_predict_workspace_bytes(nq, kq)), 16),), dtype=torch.uint8, device=device)
+    ws = torch.empty((max(int(lib.qrlsh_predict_workspace_bytes(nu, nq, kq)), 16),), dtype=torch.uint8, device=device)
     _lib.check(lib.qrlsh_predict(_ptr(r), nu, nq, _ptr(q_off), _ptr(q_idx), _ptr(q_val), _ptr(u_idx), _ptr(u_val),
                                  ui.shape[1] if ku else 0, float(query_weight), float(user_weight), float(default_mean),
                                  _lib.SUM_SEQUENTIAL if sum_order == "sequential" else _lib.SUM_PAIRWISE,

@@ -1206,7 +1206,7 @@ def test_predict_c_entry_flags_a_too_long_list_without_walking_it():
     for kq in (4, 0):
         out = torch.full((nu, nq), -7, dtype=torch.int32, device=DEV)
         flag = torch.zeros((1,), dtype=torch.int32, device=DEV)
-        ws = torch.zeros((max(16, int(lib.qrlsh_predict_workspace_bytes(nq, kq))),), dtype=torch.uint8, device=DEV)
+        ws = torch.zeros((max(16, int(lib.qrlsh_predict_workspace_bytes(nu, nq, kq))),), dtype=torch.uint8, device=DEV)
         rc = lib.qrlsh_predict(vp(d[0]), nu, nq, vp(d[1]), vp(d[2]), vp(d[3]), vp(d[4]), vp(d[5]), 0, 0.6, 0.4, 60.0,
                                _lib.SUM_PAIRWISE, vp(out), vp(flag), kq, vp(ws) if kq else None, ws.numel(), None)
         assert rc == 0
@@ -1340,6 +1340,34 @@ def test_prediction_kernel_equals_oracle_on_random_inputs():
     ratings, qs, us, coo = _random_prediction_case(rng, 80, 100, 10, 80, 0.5)
     with pytest.raises(ValueError, match="at most 64"):
         predict.fill_predictions(ratings, *coo, us, device=DEV)
+
+
+def test_prediction_row_form_stages_the_row_in_lds_or_reads_it_from_memory():
+    """the sweep's row form (one workgroup per user slice, the user's row staged in LDS as bytes) against the
+    oracle and against the CSR-form kernel, on rows that span several workgroup strides and slices; ratings beyond
+    255 (not the reference's domain, but legal int32 input) make a workgroup read its row from memory instead --
+    in some rows only, in all rows -- with the same results"""
+    from qrlsh import predict
+    rng = np.random.default_rng(77)
+    ratings, qs, us, coo = _random_prediction_case(rng, 12, 3000, 20, 6, 0.6)
+    ref = O.predict_scores(ratings, qs, us)
+    for variant in range(3):
+        r = ratings.copy()
+        if variant == 1:
+            r[3, 17] = 256; r[7, 2999] = 100000; r[9, 0] = -4           # three rows fall back
+        if variant == 2:
+            r = r * 1000                                                # every row falls back
+        want = ref if variant == 0 else O.predict_scores(r, qs, us)
+        a = predict.fill_predictions(r, *coo, us, device=DEV, transpose_lists=True)
+        b = predict.fill_predictions(r, *coo, us, device=DEV, transpose_lists=False)
+        assert np.array_equal(a.cpu().numpy(), want) and torch.equal(a, b)
+    # more users than one slice each, a row length that is no multiple of anything
+    ratings, qs, us, coo = _random_prediction_case(rng, 150, 2501, 28, 19, 0.25)
+    a = predict.fill_predictions(ratings, *coo, us, device=DEV, transpose_lists=True)
+    b = predict.fill_predictions(ratings, *coo, us, device=DEV, transpose_lists=False)
+    assert torch.equal(a, b)
+    sub = O.predict_scores(ratings, qs, us)[:3]
+    assert np.array_equal(a.cpu().numpy()[:3], sub)
 
 
 def test_answer_sets_one_sweep_equals_count_then_fill():

@@ -158,3 +158,42 @@ def test_sklearn_order_and_exact_integer_scoring_agree_at_scale(nq, D):
     m0 = O.score_pairs(sig, pairs, mode=0)
     m1 = O.score_pairs(sig, pairs, mode=1)
     assert np.array_equal(m0, m1), "%d of %d pairs round differently" % (int((m0 != m1).sum()), len(pairs))
+
+
+def test_n4_exact_integer_cosine_and_sklearn_order_agree_on_100000_column_rows():
+    """N4 (recommender.py:263-272) at the bench shape -- 2000 users x 100 000 queries, 40 clusters of 50 users:
+    the reference's own call, np.around(cosine_similarity(c_scores), 3) on the truncated centred integer rows
+    (sklearn: normalise each row in float64, then a BLAS Gram matrix over 100 000 columns), against the
+    exact-integer form the device computes (qrlsh/users.py -> qrlsh_score_pairs: int64 dot / (sqrt(na) *
+    sqrt(nb)) in float64, rint(. * 1000)) on EVERY pair of every cluster.  The float summation error of a
+    100 000-term dot product is far larger than at P = 128; a pair that rounds differently would be a parity
+    finding for qrlsh/users.py."""
+    from sklearn.metrics.pairwise import cosine_similarity
+    rng = np.random.RandomState(7)
+    nu, nq, ncl = 2000, 100_000, 40
+    labels = rng.randint(0, ncl, size=nu)
+    flips = total = 0
+    for c in range(ncl):
+        members = np.flatnonzero(labels == c)
+        block = rng.randint(1, 101, size=(len(members), nq)).astype(np.int64)
+        block[rng.rand(len(members), nq) < 0.75] = 0
+        if c % 4 == 0:       # correlated users: a shared taste vector, so that cosines leave the neighbourhood of 0
+            base = rng.randint(1, 101, size=nq)
+            keep = rng.rand(len(members), nq) < 0.5
+            block = np.where((block != 0) & keep, base[None, :], block)
+        for s in range(len(block)):                         # the reference's in-place centring in an INTEGER array
+            nz = block[s] != 0
+            block[s][nz] = block[s][nz] - np.mean(block[s][nz])
+        ref = np.around(cosine_similarity(block), 3)        # recommender.py:270
+        gram = block @ block.T                              # exact in int64: |c| <= 100, 1e5 terms
+        norm = np.sqrt(np.diag(gram).astype(np.float64))
+        with np.errstate(invalid="ignore", divide="ignore"):
+            cos = gram.astype(np.float64) / (norm[:, None] * norm[None, :])
+        cos[~np.isfinite(cos)] = 0.0
+        milli = np.rint(cos * 1000.0)
+        iu = np.triu_indices(len(members), 1)
+        total += len(iu[0])
+        flips += int((milli[iu] / 1000.0 != ref[iu]).sum())
+        assert np.abs(ref[iu]).max() > (0.05 if c % 4 == 0 else 0.0)
+    assert total > 45_000
+    assert flips == 0, "%d of %d pairs round differently" % (flips, total)
