@@ -27,8 +27,8 @@ template <typename SigT> struct ChunkOf;
 template <> struct ChunkOf<uint16_t> { typedef u16x8 type; };
 template <> struct ChunkOf<int32_t> { typedef i32x4 type; };
 
-__device__ static inline void chunk_dot(const u16x8 x, const u16x8 y, bool own_norms, int64_t &dot, int64_t &na,
-                                        int64_t &nb) {
+__device__ static inline void chunk_dot(const u16x8 x, const u16x8 y, bool sum_na, bool sum_nb, int64_t &dot,
+                                        int64_t &na, int64_t &nb) {
   // no value of either chunk has bit 15 set (always so for D <= 32768 and non-empty answer sets; 0xFFFF,
   // the -1 of an empty set, has it): four products then fit 32 bits and v_dot2_u32_u16 sums two element
   // pairs per instruction on the packed words as loaded -- ~20 instructions per lane instead of ~45
@@ -41,17 +41,20 @@ __device__ static inline void chunk_dot(const u16x8 x, const u16x8 y, bool own_n
     s0 = __builtin_amdgcn_udot2(__builtin_shufflevector(x, x, 4, 5), __builtin_shufflevector(y, y, 4, 5), s0, false);
     s1 = __builtin_amdgcn_udot2(__builtin_shufflevector(x, x, 6, 7), __builtin_shufflevector(y, y, 6, 7), s1, false);
     dot += (int64_t)((uint64_t)s0 + (uint64_t)s1);
-    if (own_norms) {
-      uint32_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+    if (sum_na) {
+      uint32_t a0 = 0, a1 = 0;
       a0 = __builtin_amdgcn_udot2(__builtin_shufflevector(x, x, 0, 1), __builtin_shufflevector(x, x, 0, 1), a0, false);
       a1 = __builtin_amdgcn_udot2(__builtin_shufflevector(x, x, 2, 3), __builtin_shufflevector(x, x, 2, 3), a1, false);
       a0 = __builtin_amdgcn_udot2(__builtin_shufflevector(x, x, 4, 5), __builtin_shufflevector(x, x, 4, 5), a0, false);
       a1 = __builtin_amdgcn_udot2(__builtin_shufflevector(x, x, 6, 7), __builtin_shufflevector(x, x, 6, 7), a1, false);
+      na += (int64_t)((uint64_t)a0 + (uint64_t)a1);
+    }
+    if (sum_nb) {
+      uint32_t b0 = 0, b1 = 0;
       b0 = __builtin_amdgcn_udot2(__builtin_shufflevector(y, y, 0, 1), __builtin_shufflevector(y, y, 0, 1), b0, false);
       b1 = __builtin_amdgcn_udot2(__builtin_shufflevector(y, y, 2, 3), __builtin_shufflevector(y, y, 2, 3), b1, false);
       b0 = __builtin_amdgcn_udot2(__builtin_shufflevector(y, y, 4, 5), __builtin_shufflevector(y, y, 4, 5), b0, false);
       b1 = __builtin_amdgcn_udot2(__builtin_shufflevector(y, y, 6, 7), __builtin_shufflevector(y, y, 6, 7), b1, false);
-      na += (int64_t)((uint64_t)a0 + (uint64_t)a1);
       nb += (int64_t)((uint64_t)b0 + (uint64_t)b1);
     }
   } else {
@@ -59,21 +62,17 @@ __device__ static inline void chunk_dot(const u16x8 x, const u16x8 y, bool own_n
     for (int e = 0; e < 8; ++e) {
       const int64_t xe = c16(x[e]), ye = c16(y[e]);
       dot += xe * ye;
-      if (own_norms) {
-        na += xe * xe;
-        nb += ye * ye;
-      }
+      if (sum_na) na += xe * xe;
+      if (sum_nb) nb += ye * ye;
     }
   }
 }
 
-__device__ static inline void chunk_dot(const i32x4 x, const i32x4 y, bool own_norms, int64_t &dot, int64_t &na,
-                                        int64_t &nb) {
+__device__ static inline void chunk_dot(const i32x4 x, const i32x4 y, bool sum_na, bool sum_nb, int64_t &dot,
+                                        int64_t &na, int64_t &nb) {
   dot += (int64_t)x.x * y.x + (int64_t)x.y * y.y + (int64_t)x.z * y.z + (int64_t)x.w * y.w;
-  if (own_norms) {
-    na += (int64_t)x.x * x.x + (int64_t)x.y * x.y + (int64_t)x.z * x.z + (int64_t)x.w * x.w;
-    nb += (int64_t)y.x * y.x + (int64_t)y.y * y.y + (int64_t)y.z * y.z + (int64_t)y.w * y.w;
-  }
+  if (sum_na) na += (int64_t)x.x * x.x + (int64_t)x.y * x.y + (int64_t)x.z * x.z + (int64_t)x.w * x.w;
+  if (sum_nb) nb += (int64_t)y.x * y.x + (int64_t)y.y * y.y + (int64_t)y.z * y.z + (int64_t)y.w * y.w;
 }
 
 // pairs a 16-lane group has in flight (their row loads are issued together).  Measured at 10 M queries (45 M pairs,
@@ -105,6 +104,13 @@ __global__ __launch_bounds__(256) void score_pairs_kernel(const SigT *__restrict
   // norm2 == NULL: the two squared norms are summed from the rows themselves, which are in registers anyway -- a
   // precomputed norm is one more random 64-B sector per row fetched (a quarter of a compact 256-B row on top)
   const bool own_norms = norm2 == nullptr;
+  // With precomputed norms: the pairs arrive sorted by i, so norm2[i] of consecutive pairs is the same word (cache), while
+  // norm2[j] is a random 64-byte sector per pair for 8 bytes.  QR_SCORE_NB_INLINE: read norm2[i], sum j's norm from its
+  // row (vector path only).
+#ifndef QR_SCORE_NB_INLINE
+#define QR_SCORE_NB_INLINE 0
+#endif
+  const bool sum_na = own_norms, sum_nb = own_norms || (QR_SCORE_NB_INLINE && VECLOAD);
   // software prefetch of the next pair words
   uint64_t pr_next[SCORE_U];
 #pragma unroll
@@ -135,7 +141,7 @@ __global__ __launch_bounds__(256) void score_pairs_kernel(const SigT *__restrict
     for (int u = 0; u < SCORE_U; ++u)
       if (!own_norms && live[u] && lig == 0) {
         na[u] = pi[u] < split ? norm2[pi[u]] : norm2_b[pi[u] - split];
-        nb[u] = pj[u] < split ? norm2[pj[u]] : norm2_b[pj[u] - split];
+        if (!sum_nb) nb[u] = pj[u] < split ? norm2[pj[u]] : norm2_b[pj[u] - split];
       }
     if (VECLOAD) {
       typedef typename ChunkOf<SigT>::type Chunk;
@@ -150,7 +156,7 @@ __global__ __launch_bounds__(256) void score_pairs_kernel(const SigT *__restrict
           y[u] = *reinterpret_cast<const Chunk *>((live[u] ? c[u] : c[0]) + col);
         }
 #pragma unroll
-        for (int u = 0; u < SCORE_U; ++u) chunk_dot(x[u], y[u], own_norms, dot[u], na[u], nb[u]);
+        for (int u = 0; u < SCORE_U; ++u) chunk_dot(x[u], y[u], sum_na, sum_nb, dot[u], na[u], nb[u]);
       }
     } else {
       for (int col = lig; col < P; col += SCORE_LPP) {
@@ -171,12 +177,13 @@ __global__ __launch_bounds__(256) void score_pairs_kernel(const SigT *__restrict
     for (int u = 0; u < SCORE_U; ++u) {
 #pragma unroll
       for (int m = 1; m < SCORE_LPP; m <<= 1) dot[u] += __shfl_xor(dot[u], m, WAVE);
-      if (own_norms) {  // uniform
+      if (sum_na) {  // uniform
 #pragma unroll
-        for (int m = 1; m < SCORE_LPP; m <<= 1) {
-          na[u] += __shfl_xor(na[u], m, WAVE);
-          nb[u] += __shfl_xor(nb[u], m, WAVE);
-        }
+        for (int m = 1; m < SCORE_LPP; m <<= 1) na[u] += __shfl_xor(na[u], m, WAVE);
+      }
+      if (sum_nb) {  // uniform
+#pragma unroll
+        for (int m = 1; m < SCORE_LPP; m <<= 1) nb[u] += __shfl_xor(nb[u], m, WAVE);
       }
     }
 #pragma unroll
