@@ -763,8 +763,14 @@ QRLSH_EXPORT int qrlsh_owner_bounds(const uint64_t *words, int64_t n, int32_t bi
 // Count-then-fill like the general path; a part larger than FIN_CAP records (heavily skewed
 // data) raises the overflow word and the host falls back to the general sort path.
 // ==========================================================================================
-constexpr int FIN_THREADS = 1024;
-constexpr int FIN_CAP = 6144;   // records per part that fit the LDS image
+#ifndef QR_FIN_THREADS
+#define QR_FIN_THREADS 1024
+#endif
+#ifndef QR_FIN_CAP
+#define QR_FIN_CAP 6144
+#endif
+constexpr int FIN_THREADS = QR_FIN_THREADS;
+constexpr int FIN_CAP = QR_FIN_CAP;   // records per part that fit the LDS image
 constexpr int FIN_IPT = FIN_CAP / FIN_THREADS;
 
 // starts[band][f] = first position of band `band` whose T-bit part number is >= f (f = 0 .. 2^T)
@@ -807,6 +813,33 @@ __device__ static inline uint32_t fin_home(uint64_t key) {
   return __umulhi(h, (uint32_t)FIN_CAP);
 }
 
+// The pairs of one record with the `c` ids at run[0 .. c) go to dst[pos .. pos + c).  A short run is written by the
+// record's own lane; a long one (a popular key: hundreds to thousands of bucket-mates) by the whole wave, lane t
+// writing pair t, t + 64, ... -- consecutive lanes write consecutive words instead of each lane walking thousands
+// of words a long stride apart.  Called by every lane of the wave (c = 0 for lanes without a record).
+constexpr uint32_t FIN_COOP = 48;
+__device__ static inline void emit_run(uint64_t *__restrict__ dst, uint32_t pos, uint32_t me, const uint32_t *run,
+                                       uint32_t run_off, uint32_t c) {
+  if (c <= FIN_COOP) {
+    for (uint32_t t = 0; t < c; ++t) {
+      const uint32_t other = run[run_off + t];
+      dst[pos + t] = (uint64_t)min(me, other) << 32 | max(me, other);
+    }
+  }
+  uint64_t big = __ballot(c > FIN_COOP);
+  const int lane = threadIdx.x & (WAVE - 1);
+  while (big) {  // uniform
+    const int L = __ffsll((long long)big) - 1;
+    big &= big - 1;
+    const uint32_t me_b = __shfl(me, L, WAVE), c_b = __shfl(c, L, WAVE), off_b = __shfl(run_off, L, WAVE),
+                   pos_b = __shfl(pos, L, WAVE);
+    for (uint32_t t = lane; t < c_b; t += WAVE) {
+      const uint32_t other = run[off_b + t];
+      dst[pos_b + t] = (uint64_t)min(me_b, other) << 32 | max(me_b, other);
+    }
+  }
+}
+
 // MODE: FIN_COUNT leaves the part's pair count in blk; FIN_FILL writes the pairs at the offset the
 // scanned blk holds; FIN_EMIT does both in one go -- the workgroup reserves its output range with
 // one atomicAdd on a global cursor (blk[0]) and writes only if the range fits `capacity`; the cursor
@@ -822,7 +855,10 @@ __global__ __launch_bounds__(FIN_THREADS, 8) void bucket_finish_kernel(const uin
                                                                        uint64_t *__restrict__ out,
                                                                        uint64_t capacity,
                                                                        const uint32_t *__restrict__ counts = nullptr,
-                                                                       uint32_t cap = 0) {
+                                                                       uint32_t cap = 0,
+                                                                       uint64_t *__restrict__ biglist = nullptr,
+                                                                       unsigned long long *__restrict__ nbig = nullptr,
+                                                                       uint32_t big_max = 0, uint32_t big_base = 0) {
   constexpr bool FILL = MODE != FIN_COUNT;
   __shared__ unsigned long long gbase;
   __shared__ __attribute__((aligned(16))) unsigned long long tab[FIN_CAP];
@@ -838,7 +874,18 @@ __global__ __launch_bounds__(FIN_THREADS, 8) void bucket_finish_kernel(const uin
   const size_t first = counts ? bslot * cap : (size_t)band * nq + start;
   if (m > (uint32_t)FIN_CAP || (counts && m > cap)) {  // uniform over the workgroup
     if (tid == 0) {
-      atomicOr(overflow, 1u);
+      // a part that holds more records than the LDS image (a popular key with thousands of copies, mostly) but
+      // fits its region: left to bucket_finish_big_kernel, which works it in blocks -- one-pass form only
+      bool listed = false;
+      if (MODE == FIN_EMIT && biglist && counts && m <= cap) {
+        const unsigned long long at =
+            __hip_atomic_fetch_add(nbig, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (at < (unsigned long long)big_max) {
+          biglist[at] = (uint64_t)(big_base + bslot);
+          listed = true;
+        }
+      }
+      if (!listed) atomicOr(overflow, 1u);
       if (MODE == FIN_COUNT) blk[bslot] = 0;
     }
     return;
@@ -964,14 +1011,186 @@ __global__ __launch_bounds__(FIN_THREADS, 8) void bucket_finish_kernel(const uin
     uint32_t pos = pos0;
 #pragma unroll
     for (int j = 0; j < FIN_IPT; ++j) {
-      if (so[j] != 0xFFFFFFFFu) {
-        const uint32_t o = so[j] >> 16, me = ireg[j];
-        const uint32_t *run = grp + cnt[so[j] & 0xFFFFu];
-        for (uint32_t t = 0; t < o; ++t) {
-          const uint32_t other = run[t];
-          dst[pos + t] = (uint64_t)min(me, other) << 32 | max(me, other);
+      const bool rec = so[j] != 0xFFFFFFFFu;
+      const uint32_t o = rec ? so[j] >> 16 : 0u;
+      emit_run(dst, pos, ireg[j], grp, rec ? cnt[so[j] & 0xFFFFu] : 0u, o);
+      pos += o;
+    }
+  }
+}
+
+// Parts the kernel above listed (more records than its LDS image, all inside their region): worked in BLOCKS of
+// FIN_CAP records by workgroups that walk the device-side list (fixed grid; nothing is read back to size the
+// launch).  Block bi is finished exactly like a small part (hash table on the full word, arrival numbers, bucket
+// runs laid out in LDS -> its own pairs); then every EARLIER block's records are streamed past bi's table: a
+// record whose word is in the table pairs with every id of that bucket's run.  Together: every pair of equal words
+// of the part, once -- a key with any number of copies up to the region's size is no special case any more.
+// Output ranges are reserved on the same device cursor as the small parts'.
+constexpr int FIN_BIG_GRID = 256;
+constexpr int FIN_BIG_FACTOR = 3;      // a part's region holds this many LDS images
+constexpr uint32_t FIN_BIG_LIST = 65536;  // listed parts per call; beyond: overflow flag (general path)
+__global__ __launch_bounds__(FIN_THREADS) void bucket_finish_big_kernel(
+    const uint64_t *__restrict__ keys, const uint32_t *__restrict__ ids, const uint32_t *__restrict__ counts, uint32_t cap,
+    uint64_t ek, const uint64_t *__restrict__ biglist, const unsigned long long *__restrict__ nbig, uint32_t big_max,
+    uint64_t *__restrict__ blk, uint64_t *__restrict__ out, uint64_t capacity) {
+  __shared__ unsigned long long gbase;
+  __shared__ __attribute__((aligned(16))) unsigned long long tab[FIN_CAP];
+  __shared__ uint32_t cnt[FIN_CAP + 1];
+  __shared__ uint32_t grp[FIN_CAP];
+  __shared__ uint32_t wsum[FIN_THREADS / WAVE];
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid >> 6;
+  unsigned long long nb = *nbig;
+  if (nb > big_max) nb = big_max;
+  // block exclusive scan of one u32 per thread -> (exclusive prefix, total); two barriers
+  auto scan = [&](uint32_t v, uint32_t &total) -> uint32_t {
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+      const uint32_t o = __shfl_up(inc, d, WAVE);
+      if (lane >= d) inc += o;
+    }
+    __syncthreads();  // wsum may still be read from the previous scan
+    if (lane == WAVE - 1) wsum[w] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < FIN_THREADS / WAVE; ++i) {
+      const uint32_t x = wsum[i];
+      if (i < w) base += x;
+      tot += x;
+    }
+    total = tot;
+    return base + inc - v;
+  };
+  // work items: (listed part, block bi, block bj <= bi) -- the table of bi is built, then bi's own pairs (bj = bi)
+  // or the pairs of bj's records with it are written; a part's items run on different workgroups
+  constexpr int COMBOS = FIN_BIG_FACTOR * (FIN_BIG_FACTOR + 1) / 2;
+  for (unsigned long long item = blockIdx.x; item < nb * COMBOS; item += gridDim.x) {
+    const unsigned long long e = item / COMBOS;
+    int combo = (int)(item - e * COMBOS);
+    uint32_t bi = 0;
+    while (combo > (int)bi) {  // combos in the order (0,0) (1,0) (1,1) (2,0) (2,1) (2,2)
+      combo -= (int)bi + 1;
+      ++bi;
+    }
+    const uint32_t bj_only = (uint32_t)combo;
+    const size_t bslot = (size_t)biglist[e];
+    const uint32_t m = min(counts[bslot], cap);
+    const uint64_t *k = keys + bslot * cap;
+    const uint32_t *id = ids + bslot * cap;
+    const uint32_t nblk = (m + FIN_CAP - 1) / FIN_CAP;
+    if (bi >= nblk) continue;  // uniform
+    {
+      const uint32_t lo = bi * FIN_CAP, mb = min((uint32_t)FIN_CAP, m - lo);
+      uint64_t kreg[FIN_IPT];
+      uint32_t ireg[FIN_IPT], so[FIN_IPT];
+      __syncthreads();  // the previous block / part is done with the arrays
+#pragma unroll
+      for (int j = 0; j < FIN_IPT; ++j) {
+        const uint32_t i = tid + j * FIN_THREADS;
+        kreg[j] = i < mb ? k[lo + i] : ek;
+        ireg[j] = i < mb ? id[lo + i] : 0u;
+        tab[i] = ek;
+        cnt[i] = 0;
+      }
+      __syncthreads();
+      uint32_t mine = 0;
+#pragma unroll
+      for (int j = 0; j < FIN_IPT; ++j) {
+        so[j] = 0xFFFFFFFFu;
+        if (kreg[j] != ek) {
+          uint32_t slot = fin_home(kreg[j]);
+          for (;;) {  // at most FIN_CAP records for FIN_CAP slots: a free one always turns up
+            const unsigned long long old = atomicCAS(&tab[slot], (unsigned long long)ek, (unsigned long long)kreg[j]);
+            if (old == ek || old == kreg[j]) break;
+            slot = slot + 1 == (uint32_t)FIN_CAP ? 0u : slot + 1;
+          }
+          const uint32_t o = atomicAdd(&cnt[slot], 1u);
+          so[j] = o << 16 | slot;
+          mine += o;
         }
-        pos += o;
+      }
+      uint32_t tot;
+      const uint32_t pos0 = scan(mine, tot);  // (its barriers also end the inserts)
+      {
+        // run starts: exclusive scan of the slot counters, blocked layout; cnt[FIN_CAP] = the block's record count
+        const uint32_t b0 = tid * FIN_IPT;
+        uint32_t v[FIN_IPT], sum = 0;
+#pragma unroll
+        for (int q = 0; q < FIN_IPT; ++q) {
+          v[q] = cnt[b0 + q];
+          sum += v[q];
+        }
+        uint32_t all;
+        uint32_t run = scan(sum, all);
+#pragma unroll
+        for (int q = 0; q < FIN_IPT; ++q) {
+          cnt[b0 + q] = run;
+          run += v[q];
+        }
+        if (tid == 0) cnt[FIN_CAP] = all;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < FIN_IPT; ++j)
+        if (so[j] != 0xFFFFFFFFu) grp[cnt[so[j] & 0xFFFFu] + (so[j] >> 16)] = ireg[j];
+      if (tid == 0 && tot && bj_only == bi)
+        gbase = __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(blk), (unsigned long long)tot, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      if (bj_only == bi && tot && gbase + tot <= capacity) {  // uniform; counted either way
+        uint64_t *dst = out + gbase;
+        uint32_t pos = pos0;
+#pragma unroll
+        for (int j = 0; j < FIN_IPT; ++j) {
+          const bool rec = so[j] != 0xFFFFFFFFu;
+          const uint32_t o = rec ? so[j] >> 16 : 0u;
+          emit_run(dst, pos, ireg[j], grp, rec ? cnt[so[j] & 0xFFFFu] : 0u, o);
+          pos += o;
+        }
+      }
+      // the records of an earlier block against this block's table
+      if (bj_only < bi) {
+        const uint32_t bj = bj_only;
+        const uint32_t lo2 = bj * FIN_CAP;  // earlier blocks are full
+        uint32_t hit[FIN_IPT];              // slot of the record's word in the table, 0xFFFFFFFF = absent
+        uint32_t mine2 = 0;
+#pragma unroll
+        for (int j = 0; j < FIN_IPT; ++j) {
+          const uint32_t i = tid + j * FIN_THREADS;
+          const uint64_t x = k[lo2 + i];
+          ireg[j] = id[lo2 + i];
+          uint32_t slot = fin_home(x), found = 0xFFFFFFFFu;
+          for (int step = 0; step < FIN_CAP; ++step) {  // (bounded: a full table has no free slot to stop at)
+            const unsigned long long tv = tab[slot];
+            if (tv == x) {
+              found = slot;
+              break;
+            }
+            if (tv == ek) break;
+            slot = slot + 1 == (uint32_t)FIN_CAP ? 0u : slot + 1;
+          }
+          hit[j] = found;
+          if (found != 0xFFFFFFFFu) mine2 += cnt[found + 1] - cnt[found];
+        }
+        uint32_t tot2;
+        const uint32_t p0 = scan(mine2, tot2);
+        if (tid == 0 && tot2)
+          gbase = __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(blk), (unsigned long long)tot2,
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (tot2 && gbase + tot2 <= capacity) {  // uniform
+          uint64_t *dst = out + gbase;
+          uint32_t pos = p0;
+#pragma unroll
+          for (int j = 0; j < FIN_IPT; ++j) {
+            const bool h = hit[j] != 0xFFFFFFFFu;
+            const uint32_t s0 = h ? cnt[hit[j]] : 0u, c = h ? cnt[hit[j] + 1] - s0 : 0u;
+            emit_run(dst, pos, ireg[j], grp, s0, c);
+            pos += c;
+          }
+        }
+        __syncthreads();  // gbase is rewritten by the next reservation
       }
     }
   }
@@ -1103,7 +1322,9 @@ QRLSH_EXPORT int qrlsh_bucket_pairs_count(const uint64_t *keys, uint64_t *part_k
 // finish for full-size inputs, mean + 50 % + 512 for small ones
 static uint32_t part_region(int64_t nq) {
   const int64_t c = ((nq / RADIX) * 3 / 2 + 512 + 63) / 64 * 64;
-  return (uint32_t)(c < FIN_CAP ? c : FIN_CAP);
+  // full-size inputs: room for FIN_BIG_FACTOR images, so that a part swollen by a popular key stays inside its
+  // region and goes to bucket_finish_big_kernel instead of sending the whole step to the general path
+  return (uint32_t)(c < FIN_CAP ? c : FIN_BIG_FACTOR * FIN_CAP);
 }
 
 // finer partitions (T > 8) go through two such kernels: 2^c1 coarse regions per band, then 2^(T-c1) fine
@@ -1121,7 +1342,7 @@ static uint32_t coarse_region(int64_t nq, int c1) {
 static uint32_t fine_region(int64_t nq, int T) {
   // real sizes (mean >= 1024 records per part): the whole LDS image, so that a popular key with a few
   // thousand copies still fits its part, as in the sort-based partition; tiny inputs: 2 x mean + 128
-  if ((nq >> T) >= 1024) return FIN_CAP;
+  if ((nq >> T) >= 1024) return FIN_BIG_FACTOR * FIN_CAP;
   const int64_t c = ((nq >> T) * 2 + 128 + 63) / 64 * 64;
   return (uint32_t)(c < FIN_CAP ? c : FIN_CAP);
 }
@@ -1201,6 +1422,15 @@ QRLSH_EXPORT int qrlsh_bucket_pairs_emit_chunked(const uint64_t *keys, int64_t k
       return QRLSH_EHIP;
     }
     uint32_t *ovf = reinterpret_cast<uint32_t *>(total_overflow_out + 1);
+    // list of the parts that outgrow the LDS image (bucket_finish_big_kernel): in the count / fill form's block area
+    uint64_t *biglist = w.blk;
+    unsigned long long *nbig = reinterpret_cast<unsigned long long *>(w.tail + 2);
+    const uint64_t slots = (uint64_t)b << T;
+    const uint32_t big_max = (uint32_t)(slots < FIN_BIG_LIST ? slots : FIN_BIG_LIST);
+    if (hipMemsetAsync(nbig, 0, sizeof(unsigned long long), st) != hipSuccess) {
+      qrlsh_set_error("qrlsh_bucket_pairs_emit: hipMemsetAsync failed");
+      return QRLSH_EHIP;
+    }
     const int ntiles = (int)ceil_div64(nq, PS_TILE);
     const int64_t band_words = key_band_stride ? key_band_stride : nq;  // words between two bands of the key matrix
     static int groups_env = -1;
@@ -1236,9 +1466,13 @@ QRLSH_EXPORT int qrlsh_bucket_pairs_emit_chunked(const uint64_t *keys, int64_t k
       QR_LAUNCH("bucket_emit", (bucket_finish_kernel<FIN_EMIT>), dim3(nparts, nb), dim3(FIN_THREADS), 0, s,
                 (const uint64_t *)part_keys + ((size_t)g0 << T) * cap2, (const uint32_t *)part_ids + ((size_t)g0 << T) * cap2,
                 nq, (const uint32_t *)nullptr, nparts, ekx, total_overflow_out, ovf, pairs_out, capacity,
-                (const uint32_t *)cur2 + ((size_t)g0 << T), cap2);
+                (const uint32_t *)cur2 + ((size_t)g0 << T), cap2, biglist, nbig, big_max, (uint32_t)((size_t)g0 << T));
     }
     if (aux) qr_aux_join(st);
+    // the parts the finish listed as larger than its LDS image (usually none: the kernel then finds an empty list)
+    QR_LAUNCH("bucket_emit_big", bucket_finish_big_kernel, dim3(FIN_BIG_GRID), dim3(FIN_THREADS), 0, st,
+              (const uint64_t *)part_keys, (const uint32_t *)part_ids, (const uint32_t *)cur2, cap2, ekx,
+              (const uint64_t *)biglist, (const unsigned long long *)nbig, big_max, total_overflow_out, pairs_out, capacity);
     QR_LAUNCH_CHECK("qrlsh_bucket_pairs_emit");
     return QRLSH_OK;
   }

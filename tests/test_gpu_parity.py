@@ -795,8 +795,13 @@ def test_config4_rank_slice():
     del keys
     # 3. pairs of the owned bands over all ids, from the exchanged layout in place
     #    (the product call: the partition + LDS finish, or -- when a part overflows its LDS image -- the general sort path)
+    import time
     be = qdist.HipBackend()
+    torch.cuda.synchronize()
+    t_emit = time.perf_counter()
     emitted = be.emit_pairs_chunked(recv.view(-1), world, nb, nql, r)
+    torch.cuda.synchronize()
+    t_emit = time.perf_counter() - t_emit
     assert ops.part_bits_for(nq) == 15
     bucket_path = be.stats["bucket_path"]
     n_emitted = emitted.numel()
@@ -850,8 +855,8 @@ def test_config4_rank_slice():
     assert ib == 27 and ops.wide_ids(ib)
     ek, ed = ops.pair_edges_interleaved(pairs, milli, ib, wide=True)
     assert ek.numel() == 2 * pairs.numel() and ed.numel() == 2 * pairs.numel()
-    print("configs[4] rank slice: bucket path %s, emitted %d, hosted here %d unique, remote rows %d"
-          % (bucket_path, n_emitted, len(hp), len(hn)))
+    print("configs[4] rank slice: bucket path %s (%.1f ms for the 8 owned bands x 100 M ids), emitted %d, hosted here %d "
+          "unique, remote rows %d" % (bucket_path, t_emit * 1e3, n_emitted, len(hp), len(hn)))
     del sig_all, norm_all, recv
     torch.cuda.empty_cache()
 
@@ -974,6 +979,35 @@ def test_chunked_key_layout_is_read_in_place(nq, b, world, T):
     chunked = ops.emit_pairs_fast(dev(recv.view(np.int64)), 4, part_bits=T, chunks=(world, b, nql))
     assert plain is not None and chunked is not None and chunked.numel() == plain.numel()
     assert np.array_equal(np.sort(u64(chunked)), np.sort(u64(plain)))
+
+
+def test_popular_keys_beyond_the_lds_image_stay_on_the_fast_path():
+    """lsh.py:42-53 on buckets with thousands of members (at 100 M queries over D = 32768 rows a band key that is
+    minimal in all its permutations is shared by ~8 000 unrelated queries: configs[4]).  A part whose records
+    outgrow the finish kernel's LDS image but fit its region (three images) is worked in blocks by
+    bucket_finish_big_kernel: 7 000 copies (two blocks), 13 000 copies (three blocks, cross joins between all of
+    them), beside ordinary small buckets -- exact against the oracle, and without leaving the partition + LDS path.
+    A key with more copies than a region holds still takes the general path, with the same result."""
+    nq, b, r = 1_000_000, 2, 4
+    rng = np.random.default_rng(21)
+    for heavy, want_path in [((7000, 13000), "partition+lds"), ((7000, 40000), "general-sort")]:
+        keys = rng.integers(1, 1 << 62, size=(b, nq), dtype=np.int64)
+        for band in range(b):                                   # ordinary buckets of 2 .. 5 members
+            for size in (2, 3, 5):
+                ids = rng.choice(nq, size=(2000, size), replace=False)
+                keys[band, ids] = rng.integers(1, 1 << 62, size=(2000, 1), dtype=np.int64)
+        for band, n in enumerate(heavy):
+            keys[band, rng.choice(nq, size=n, replace=False)] = 0x1234567 + band
+        stats = {}
+        emitted = ops.emit_pairs_any(dev(keys), r, stats)
+        assert stats["bucket_path"] == want_path
+        kq = np.ascontiguousarray(keys.T).view(np.uint64)
+        want = O.candidates(kq, r)
+        assert emitted.numel() == O.emitted_pairs(kq, r) >= sum(n * (n - 1) // 2 for n in heavy)
+        got = np.unique(u64(emitted))
+        assert np.array_equal(got, want)          # (a pair of queries that share both bands' heavy keys is emitted twice)
+        del emitted
+        torch.cuda.empty_cache()
 
 
 def test_overflowing_part_falls_back_to_general_path():
