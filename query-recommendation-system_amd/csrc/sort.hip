@@ -817,7 +817,11 @@ __device__ static inline uint32_t fin_home(uint64_t key) {
 // record's own lane; a long one (a popular key: hundreds to thousands of bucket-mates) by the whole wave, lane t
 // writing pair t, t + 64, ... -- consecutive lanes write consecutive words instead of each lane walking thousands
 // of words a long stride apart.  Called by every lane of the wave (c = 0 for lanes without a record).
-constexpr uint32_t FIN_COOP = 48;
+// Threshold, 10 M queries x 32 bands (same box): never cooperative 2.88 ms for the finish, 48 -> 2.56, 12 -> 2.52.
+#ifndef QR_FIN_COOP
+#define QR_FIN_COOP 16
+#endif
+constexpr uint32_t FIN_COOP = QR_FIN_COOP;
 __device__ static inline void emit_run(uint64_t *__restrict__ dst, uint32_t pos, uint32_t me, const uint32_t *run,
                                        uint32_t run_off, uint32_t c) {
   if (c <= FIN_COOP) {
