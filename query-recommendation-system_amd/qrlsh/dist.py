@@ -105,9 +105,11 @@ class HipBackend:
         g, _ = ops.sort_u64(pairs, None, host_shard=nql)
         return g, ops.owner_bounds(g, -1, nql, world)
 
-    def sort_unique(self, words, nids):
+    def sort_unique(self, words, nids, words_per_query=None):
         # the words a rank receives touch ~2 x its own share of the ids (the other endpoint of half its pairs)
-        return ops.unique_pairs(words, nids, self.stats, words_per_query=words.numel() / max(1, 2 * (self.rows_hint or 1)))
+        if words_per_query is None:
+            words_per_query = words.numel() / max(1, 2 * (self.rows_hint or 1))
+        return ops.unique_pairs(words, nids, self.stats, words_per_query=words_per_query)
 
     def remote_ids(self, pairs, q0, nql, nids, world):
         return ops.remote_ids(pairs, q0, nql, nids, world)
@@ -277,12 +279,13 @@ class _Phases:
 
 
 def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="all_to_all", backend=None,
-                               group=None, wide_ids=None, sig_exchange="auto", phases=None):
+                               group=None, wide_ids=None, sig_exchange="auto", phases=None, local_dedup=None):
     """Hot path for this rank's query shard (the queries shard_range(nq_total, world, rank) names);
     collective over `group`.  Returns a HotPathResult: sig / norm2 / top-K rows of this rank's queries
     (global ids; concatenated over ranks in rank order they equal the single-GPU result) and the
     candidate pairs this rank scored, sorted (disjoint over ranks; their union is the single-GPU list).
-    phases: a dict that accumulates "ms:<phase>" / "bytes:<collective>" over calls (diagnostics)."""
+    phases: a dict that accumulates "ms:<phase>" / "bytes:<collective>" over calls (diagnostics).
+    local_dedup: de-duplicate the rank's own emissions before the pair exchange (None: up to four ranks)."""
     be = backend if backend is not None else HipBackend()
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
@@ -325,11 +328,18 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
         max_nnz = max(1, int(cnt.max().item()))
         rows_pad = rows if rows.numel() == max_nnz else torch.cat([rows, rows.new_zeros(max_nnz - rows.numel())])
         bg = background_group(group)
-        ra = torch.empty((world, max_nnz), dtype=torch.int32, device=dev)
-        oa = torch.empty((world, nql + 1), dtype=torch.int64, device=dev)
-        h_r = _all_gather(ra.view(-1), rows_pad, bg, async_op=True)
-        h_o = _all_gather(oa.view(-1), offsets, bg, async_op=True)
-        ph.sent("0_answer_sets", (rows_pad.numel() * 4 + offsets.numel() * 8) * (world - 1))
+        # on the wire the row ids are 16-bit words when the table has at most 65536 rows and the offsets 32-bit ones
+        # (a shard holds fewer than 2^31 row ids): 34 instead of 72 bytes per query of mean size 16 -- this gather is
+        # what a two-rank step waits for longest (one xGMI link)
+        narrow = table.D <= 65536
+        small_off = max_nnz < (1 << 31)
+        rows_w = rows_pad.to(torch.int16) if narrow else rows_pad
+        off_w = offsets.to(torch.int32) if small_off else offsets
+        ra_w = torch.empty((world, max_nnz), dtype=rows_w.dtype, device=dev)
+        oa_w = torch.empty((world, nql + 1), dtype=off_w.dtype, device=dev)
+        h_r = _all_gather(ra_w, rows_w.view(1, -1), bg, async_op=True)
+        h_o = _all_gather(oa_w, off_w.view(1, -1), bg, async_op=True)
+        ph.sent("0_answer_sets", (rows_w.numel() * rows_w.element_size() + off_w.numel() * off_w.element_size()) * (world - 1))
         # 1. signatures of ALL queries, own shard first (it runs beside the gather); every block goes straight to
         #    its place in the replicated tables when the row blocks keep the kernel's 16-byte alignment
         sdt = be.sig_dtype(table)
@@ -353,8 +363,11 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
         h_o.wait()
         for g in range(world):
             if g != rank:
-                shard_signatures(g, oa[g], ra[g], False)      # validated by their owner
-        del ra, oa, rows_pad
+                ra_g = (ra_w[g].to(torch.int32) & 0xFFFF) if narrow else ra_w[g]
+                oa_g = oa_w[g].to(torch.int64) if small_off else oa_w[g]
+                shard_signatures(g, oa_g, ra_g, False)      # validated by their owner
+                del ra_g, oa_g
+        del ra_w, oa_w, rows_pad, rows_w, off_w
         sig, norm2 = sa[q0:q0 + nql], na[q0:q0 + nql]
         keys = None
         stats["bucket_id_exchange"] = "none (answer sets replicated)"
@@ -406,8 +419,16 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
     owned = recv = keys_all = None
     ph.done("3_bucket_pairs")
 
-    # 4. pairs -> the rank that scores them.  Duplicates across this rank's few bands are left in: the
-    #    scoring rank de-duplicates anyway, a local unique would cost more passes than the bytes it saves
+    # 4. pairs -> the rank that scores them.  With many ranks (few bands each) the duplicates across this rank's own
+    #    bands are left in -- the scoring rank de-duplicates anyway and a local unique would cost more passes than the
+    #    bytes it saves; with up to four ranks (8+ of 32 bands each, ONE to three links to push everything through) a
+    #    pair that collides in several of the rank's bands is sent once: the rank's emissions are de-duplicated first
+    #    (375 -> ~140 MB out per rank and step at two ranks, 10 M queries)
+    if local_dedup is None:
+        local_dedup = 1 < world <= 4
+    if world > 1 and local_dedup and emitted.numel():
+        emitted = be.sort_unique(emitted, nids, words_per_query=emitted.numel() / max(1, nids))
+        stats["local_unique_pairs"] = int(emitted.numel())
     if world > 1:
         mine, bounds = be.group_pairs_by_host(emitted, nql, world)
         ssz, rsz = _exchange_sizes(bounds, group)

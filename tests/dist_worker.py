@@ -88,7 +88,7 @@ class OracleBackend:
         bounds = np.searchsorted(h[o], np.arange(world + 1))
         return _t(w[o].view(np.int64)), _t(bounds.astype(np.int64))
 
-    def sort_unique(self, words, nids):
+    def sort_unique(self, words, nids, words_per_query=None):
         return _t(np.unique(words.numpy().view(np.uint64)).view(np.int64))
 
     def remote_ids(self, pairs, q0, nql, nids, world):
