@@ -22,67 +22,6 @@ constexpr int SCORE_LPP = 16;  // lanes per pair
 // value of a compact uint16 signature entry: 0xFFFF is the -1 of an empty answer set
 __device__ static inline int64_t c16(unsigned short v) { return v == 0xFFFFu ? -1 : (int64_t)v; }
 
-// one 16-byte chunk of both rows of a pair: exact integer dot (and, when asked, both squared norms)
-template <typename SigT> struct ChunkOf;
-template <> struct ChunkOf<uint16_t> { typedef u16x8 type; };
-template <> struct ChunkOf<int32_t> { typedef i32x4 type; };
-
-__device__ static inline void chunk_dot(const u16x8 x, const u16x8 y, bool sum_na, bool sum_nb, int64_t &dot,
-                                        int64_t &na, int64_t &nb) {
-  // no value of either chunk has bit 15 set (always so for D <= 32768 and non-empty answer sets; 0xFFFF,
-  // the -1 of an empty set, has it): four products then fit 32 bits and v_dot2_u32_u16 sums two element
-  // pairs per instruction on the packed words as loaded -- ~20 instructions per lane instead of ~45
-  // (unpack, -1 test, 64-bit multiply-add per element).  Decided per chunk from the data, same integers.
-  const u32x4 xw = __builtin_bit_cast(u32x4, x), yw = __builtin_bit_cast(u32x4, y);
-  const uint32_t hi = (xw[0] | xw[1] | xw[2] | xw[3] | yw[0] | yw[1] | yw[2] | yw[3]) & 0x80008000u;
-  if (hi == 0) {
-    uint32_t s0 = __builtin_amdgcn_udot2(__builtin_shufflevector(x, x, 0, 1), __builtin_shufflevector(y, y, 0, 1), 0u, false);
-    uint32_t s1 = __builtin_amdgcn_udot2(__builtin_shufflevector(x, x, 2, 3), __builtin_shufflevector(y, y, 2, 3), 0u, false);
-    s0 = __builtin_amdgcn_udot2(__builtin_shufflevector(x, x, 4, 5), __builtin_shufflevector(y, y, 4, 5), s0, false);
-    s1 = __builtin_amdgcn_udot2(__builtin_shufflevector(x, x, 6, 7), __builtin_shufflevector(y, y, 6, 7), s1, false);
-    dot += (int64_t)((uint64_t)s0 + (uint64_t)s1);
-    if (sum_na) {
-      uint32_t a0 = 0, a1 = 0;
-      a0 = __builtin_amdgcn_udot2(__builtin_shufflevector(x, x, 0, 1), __builtin_shufflevector(x, x, 0, 1), a0, false);
-      a1 = __builtin_amdgcn_udot2(__builtin_shufflevector(x, x, 2, 3), __builtin_shufflevector(x, x, 2, 3), a1, false);
-      a0 = __builtin_amdgcn_udot2(__builtin_shufflevector(x, x, 4, 5), __builtin_shufflevector(x, x, 4, 5), a0, false);
-      a1 = __builtin_amdgcn_udot2(__builtin_shufflevector(x, x, 6, 7), __builtin_shufflevector(x, x, 6, 7), a1, false);
-      na += (int64_t)((uint64_t)a0 + (uint64_t)a1);
-    }
-    if (sum_nb) {
-      uint32_t b0 = 0, b1 = 0;
-      b0 = __builtin_amdgcn_udot2(__builtin_shufflevector(y, y, 0, 1), __builtin_shufflevector(y, y, 0, 1), b0, false);
-      b1 = __builtin_amdgcn_udot2(__builtin_shufflevector(y, y, 2, 3), __builtin_shufflevector(y, y, 2, 3), b1, false);
-      b0 = __builtin_amdgcn_udot2(__builtin_shufflevector(y, y, 4, 5), __builtin_shufflevector(y, y, 4, 5), b0, false);
-      b1 = __builtin_amdgcn_udot2(__builtin_shufflevector(y, y, 6, 7), __builtin_shufflevector(y, y, 6, 7), b1, false);
-      nb += (int64_t)((uint64_t)b0 + (uint64_t)b1);
-    }
-  } else {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int64_t xe = c16(x[e]), ye = c16(y[e]);
-      dot += xe * ye;
-      if (sum_na) na += xe * xe;
-      if (sum_nb) nb += ye * ye;
-    }
-  }
-}
-
-__device__ static inline void chunk_dot(const i32x4 x, const i32x4 y, bool sum_na, bool sum_nb, int64_t &dot,
-                                        int64_t &na, int64_t &nb) {
-  dot += (int64_t)x.x * y.x + (int64_t)x.y * y.y + (int64_t)x.z * y.z + (int64_t)x.w * y.w;
-  if (sum_na) na += (int64_t)x.x * x.x + (int64_t)x.y * x.y + (int64_t)x.z * x.z + (int64_t)x.w * x.w;
-  if (sum_nb) nb += (int64_t)y.x * y.x + (int64_t)y.y * y.y + (int64_t)y.z * y.z + (int64_t)y.w * y.w;
-}
-
-// pairs a 16-lane group has in flight (their row loads are issued together).  Measured at 10 M queries (45 M pairs,
-// same box, tools/ab_flags.sh): 1 -> 3.78 ms, 2 -> 4.35 ms, 3 -> 4.54 ms -- the registers of the extra rows cost
-// waves (8 -> 5 per SIMD) and the kernel wants the waves more than the loads per wave.
-#ifndef QR_SCORE_UNROLL
-#define QR_SCORE_UNROLL 1
-#endif
-constexpr int SCORE_U = QR_SCORE_UNROLL;
-
 // SigT = int32_t (reference layout) or uint16_t (compact rows, D <= 65535: half the HBM bytes)
 template <typename SigT, bool VECLOAD>
 __global__ __launch_bounds__(256) void score_pairs_kernel(const SigT *__restrict__ sig,
@@ -100,119 +39,128 @@ __global__ __launch_bounds__(256) void score_pairs_kernel(const SigT *__restrict
   const int lig = lane & (SCORE_LPP - 1);
   const int64_t group = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / SCORE_LPP);
   const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) / SCORE_LPP;
-  const int64_t iters = (n + ngroups * SCORE_U - 1) / (ngroups * SCORE_U);  // uniform trip count for the shuffles
-  // norm2 == NULL: the two squared norms are summed from the rows themselves, which are in registers anyway -- a
-  // precomputed norm is one more random 64-B sector per row fetched (a quarter of a compact 256-B row on top)
-  const bool own_norms = norm2 == nullptr;
-  // With precomputed norms: the pairs arrive sorted by i, so norm2[i] of consecutive pairs is the same word (cache), while
-  // norm2[j] is a random 64-byte sector per pair for 8 bytes.  QR_SCORE_NB_INLINE: read norm2[i], sum j's norm from its
-  // row (vector path only).
-#ifndef QR_SCORE_NB_INLINE
-#define QR_SCORE_NB_INLINE 0
-#endif
-  const bool sum_na = own_norms, sum_nb = own_norms || (QR_SCORE_NB_INLINE && VECLOAD);
-  // software prefetch of the next pair words
-  uint64_t pr_next[SCORE_U];
-#pragma unroll
-  for (int u = 0; u < SCORE_U; ++u) {
-    const int64_t t = (int64_t)u * ngroups + group;
-    pr_next[u] = t < n ? pairs[t] : 0;
-  }
+  const int64_t iters = (n + ngroups - 1) / ngroups;  // uniform trip count for the shuffles
+  // software prefetch of the next pair word
+  uint64_t pr_next = (group < n) ? pairs[group] : 0;
   for (int64_t it = 0; it < iters; ++it) {
-    int64_t t[SCORE_U], dot[SCORE_U], na[SCORE_U], nb[SCORE_U];
-    uint32_t pi[SCORE_U], pj[SCORE_U];
-    const SigT *a[SCORE_U], *c[SCORE_U];
-    bool live[SCORE_U];
-#pragma unroll
-    for (int u = 0; u < SCORE_U; ++u) {
-      t[u] = (it * SCORE_U + u) * ngroups + group;
-      live[u] = t[u] < n;
-      const uint64_t pr = pr_next[u];
-      const int64_t tn = t[u] + (int64_t)SCORE_U * ngroups;
-      pr_next[u] = tn < n ? pairs[tn] : 0;
-      pi[u] = (uint32_t)(pr >> 32);
-      pj[u] = (uint32_t)pr;
-      // row table in two pieces (sharded driver): rows below `split` are the rank's own, the rest were fetched
-      a[u] = pi[u] < split ? sig + (size_t)pi[u] * P : sig_b + (size_t)(pi[u] - split) * P;
-      c[u] = pj[u] < split ? sig + (size_t)pj[u] * P : sig_b + (size_t)(pj[u] - split) * P;
-      dot[u] = na[u] = nb[u] = 0;
+    const int64_t t = it * ngroups + group;
+    const bool live = t < n;
+    const uint64_t pr = pr_next;
+    const int64_t tn = t + ngroups;
+    pr_next = (tn < n) ? pairs[tn] : 0;
+    const uint32_t i = (uint32_t)(pr >> 32), j = (uint32_t)pr;
+    // row table in two pieces (sharded driver): rows below `split` are the rank's own, the rest were fetched
+    const SigT *a = i < split ? sig + (size_t)i * P : sig_b + (size_t)(i - split) * P;
+    const SigT *c = j < split ? sig + (size_t)j * P : sig_b + (size_t)(j - split) * P;
+    // norm2 == NULL: the two squared norms are summed from the rows themselves, which are in registers anyway -- a
+    // precomputed norm is one more random 64-B sector per row fetched (a quarter of a compact 256-B row on top)
+    const bool own_norms = norm2 == nullptr;
+    int64_t na = 0, nb = 0;
+    if (!own_norms && live && lig == 0) {
+      na = i < split ? norm2[i] : norm2_b[i - split];
+      nb = j < split ? norm2[j] : norm2_b[j - split];
     }
+    int64_t dot = 0;
+    if (live) {
+      if (VECLOAD) {
+        for (int col = lig * VEC; col < P; col += SCORE_LPP * VEC) {
+          if (IS16) {
+            const u16x8 x = *reinterpret_cast<const u16x8 *>(a + col);
+            const u16x8 y = *reinterpret_cast<const u16x8 *>(c + col);
+            // no value of either chunk has bit 15 set (always so for D <= 32768 and non-empty answer sets; 0xFFFF,
+            // the -1 of an empty set, has it): four products then fit 32 bits and v_dot2_u32_u16 sums two element
+            // pairs per instruction on the packed words as loaded -- ~20 instructions per lane instead of ~45
+            // (unpack, -1 test, 64-bit multiply-add per element).  Decided per chunk from the data, same integers.
+            const u32x4 xw = __builtin_bit_cast(u32x4, x), yw = __builtin_bit_cast(u32x4, y);
+            const uint32_t hi = (xw[0] | xw[1] | xw[2] | xw[3] | yw[0] | yw[1] | yw[2] | yw[3]) & 0x80008000u;
+            if (hi == 0) {
+              uint32_t s0 = __builtin_amdgcn_udot2(__builtin_shufflevector(x, x, 0, 1),
+                                                   __builtin_shufflevector(y, y, 0, 1), 0u, false);
+              uint32_t s1 = __builtin_amdgcn_udot2(__builtin_shufflevector(x, x, 2, 3),
+                                                   __builtin_shufflevector(y, y, 2, 3), 0u, false);
+              s0 = __builtin_amdgcn_udot2(__builtin_shufflevector(x, x, 4, 5), __builtin_shufflevector(y, y, 4, 5),
+                                          s0, false);
+              s1 = __builtin_amdgcn_udot2(__builtin_shufflevector(x, x, 6, 7), __builtin_shufflevector(y, y, 6, 7),
+                                          s1, false);
+              dot += (int64_t)((uint64_t)s0 + (uint64_t)s1);
+              if (own_norms) {
+                uint32_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+                a0 = __builtin_amdgcn_udot2(__builtin_shufflevector(x, x, 0, 1), __builtin_shufflevector(x, x, 0, 1), a0, false);
+                a1 = __builtin_amdgcn_udot2(__builtin_shufflevector(x, x, 2, 3), __builtin_shufflevector(x, x, 2, 3), a1, false);
+                a0 = __builtin_amdgcn_udot2(__builtin_shufflevector(x, x, 4, 5), __builtin_shufflevector(x, x, 4, 5), a0, false);
+                a1 = __builtin_amdgcn_udot2(__builtin_shufflevector(x, x, 6, 7), __builtin_shufflevector(x, x, 6, 7), a1, false);
+                b0 = __builtin_amdgcn_udot2(__builtin_shufflevector(y, y, 0, 1), __builtin_shufflevector(y, y, 0, 1), b0, false);
+                b1 = __builtin_amdgcn_udot2(__builtin_shufflevector(y, y, 2, 3), __builtin_shufflevector(y, y, 2, 3), b1, false);
+                b0 = __builtin_amdgcn_udot2(__builtin_shufflevector(y, y, 4, 5), __builtin_shufflevector(y, y, 4, 5), b0, false);
+                b1 = __builtin_amdgcn_udot2(__builtin_shufflevector(y, y, 6, 7), __builtin_shufflevector(y, y, 6, 7), b1, false);
+                na += (int64_t)((uint64_t)a0 + (uint64_t)a1);
+                nb += (int64_t)((uint64_t)b0 + (uint64_t)b1);
+              }
+            } else {
 #pragma unroll
-    for (int u = 0; u < SCORE_U; ++u)
-      if (!own_norms && live[u] && lig == 0) {
-        na[u] = pi[u] < split ? norm2[pi[u]] : norm2_b[pi[u] - split];
-        if (!sum_nb) nb[u] = pj[u] < split ? norm2[pj[u]] : norm2_b[pj[u] - split];
-      }
-    if (VECLOAD) {
-      typedef typename ChunkOf<SigT>::type Chunk;
-      for (int col = lig * VEC; col < P; col += SCORE_LPP * VEC) {
-        // every row chunk of the SCORE_U pairs is requested before the first is used (t[u] grows with u: a dead slot
-        // behind a live slot 0 re-reads slot 0's rows -- valid addresses -- and its sums are never stored)
-        if (!live[0]) break;
-        Chunk x[SCORE_U], y[SCORE_U];
-#pragma unroll
-        for (int u = 0; u < SCORE_U; ++u) {
-          x[u] = *reinterpret_cast<const Chunk *>((live[u] ? a[u] : a[0]) + col);
-          y[u] = *reinterpret_cast<const Chunk *>((live[u] ? c[u] : c[0]) + col);
-        }
-#pragma unroll
-        for (int u = 0; u < SCORE_U; ++u) chunk_dot(x[u], y[u], sum_na, sum_nb, dot[u], na[u], nb[u]);
-      }
-    } else {
-      for (int col = lig; col < P; col += SCORE_LPP) {
-#pragma unroll
-        for (int u = 0; u < SCORE_U; ++u)
-          if (live[u]) {
-            const int64_t xe = IS16 ? c16((unsigned short)a[u][col]) : (int64_t)a[u][col];
-            const int64_t ye = IS16 ? c16((unsigned short)c[u][col]) : (int64_t)c[u][col];
-            dot[u] += xe * ye;
+              for (int e = 0; e < 8; ++e) {
+                const int64_t xe = c16(x[e]), ye = c16(y[e]);
+                dot += xe * ye;
+                if (own_norms) {
+                  na += xe * xe;
+                  nb += ye * ye;
+                }
+              }
+            }
+          } else {
+            const i32x4 x = *reinterpret_cast<const i32x4 *>(a + col);
+            const i32x4 y = *reinterpret_cast<const i32x4 *>(c + col);
+            dot += (int64_t)x.x * y.x + (int64_t)x.y * y.y + (int64_t)x.z * y.z + (int64_t)x.w * y.w;
             if (own_norms) {
-              na[u] += xe * xe;
-              nb[u] += ye * ye;
+              na += (int64_t)x.x * x.x + (int64_t)x.y * x.y + (int64_t)x.z * x.z + (int64_t)x.w * x.w;
+              nb += (int64_t)y.x * y.x + (int64_t)y.y * y.y + (int64_t)y.z * y.z + (int64_t)y.w * y.w;
             }
           }
+        }
+      } else {
+        for (int col = lig; col < P; col += SCORE_LPP) {
+          const int64_t xe = IS16 ? c16((unsigned short)a[col]) : (int64_t)a[col];
+          const int64_t ye = IS16 ? c16((unsigned short)c[col]) : (int64_t)c[col];
+          dot += xe * ye;
+          if (own_norms) {
+            na += xe * xe;
+            nb += ye * ye;
+          }
+        }
       }
     }
 #pragma unroll
-    for (int u = 0; u < SCORE_U; ++u) {
+    for (int m = 1; m < SCORE_LPP; m <<= 1) dot += __shfl_xor(dot, m, WAVE);
+    if (own_norms) {  // uniform
 #pragma unroll
-      for (int m = 1; m < SCORE_LPP; m <<= 1) dot[u] += __shfl_xor(dot[u], m, WAVE);
-      if (sum_na) {  // uniform
-#pragma unroll
-        for (int m = 1; m < SCORE_LPP; m <<= 1) na[u] += __shfl_xor(na[u], m, WAVE);
-      }
-      if (sum_nb) {  // uniform
-#pragma unroll
-        for (int m = 1; m < SCORE_LPP; m <<= 1) nb[u] += __shfl_xor(nb[u], m, WAVE);
+      for (int m = 1; m < SCORE_LPP; m <<= 1) {
+        na += __shfl_xor(na, m, WAVE);
+        nb += __shfl_xor(nb, m, WAVE);
       }
     }
-#pragma unroll
-    for (int u = 0; u < SCORE_U; ++u) {
-      if (!(live[u] && lig == 0)) continue;
-      const uint32_t i = pi[u], j = pj[u];
-      const int64_t tt = t[u];
+    if (live && lig == 0) {
       double cs = 0.0;
-      if (na[u] != 0 && nb[u] != 0) cs = (double)dot[u] / (sqrt((double)na[u]) * sqrt((double)nb[u]));
+      if (na != 0 && nb != 0) cs = (double)dot / (sqrt((double)na) * sqrt((double)nb));
       const int32_t mi = (int32_t)rint(cs * 1000.0);
-      milli[tt] = mi;
-      if (cosv) cosv[tt] = cs;
+      milli[t] = mi;
+      if (cosv) cosv[t] = cs;
       if (edges) {
         const uint64_t inv = (uint64_t)(1000 - mi);
         if (rev_only) {  // only the reverse edge (src = j), one word per pair: the select form of the top-K
           if (edge_dst) {
-            edges[tt] = ((uint64_t)j << 11) | inv;
-            edge_dst[tt] = i;
+            edges[t] = ((uint64_t)j << 11) | inv;
+            edge_dst[t] = i;
           } else {
-            edges[tt] = ((uint64_t)j << (id_bits + 11)) | (inv << id_bits) | i;
+            edges[t] = ((uint64_t)j << (id_bits + 11)) | (inv << id_bits) | i;
           }
         } else if (edge_dst) {  // wide ids: src << 11 | inv in the key, dst as the payload
-          edges[2 * tt] = ((uint64_t)i << 11) | inv;
-          edges[2 * tt + 1] = ((uint64_t)j << 11) | inv;
-          edge_dst[2 * tt] = j;
-          edge_dst[2 * tt + 1] = i;
+          edges[2 * t] = ((uint64_t)i << 11) | inv;
+          edges[2 * t + 1] = ((uint64_t)j << 11) | inv;
+          edge_dst[2 * t] = j;
+          edge_dst[2 * t + 1] = i;
         } else {
-          edges[2 * tt] = ((uint64_t)i << (id_bits + 11)) | (inv << id_bits) | j;
-          edges[2 * tt + 1] = ((uint64_t)j << (id_bits + 11)) | (inv << id_bits) | i;
+          edges[2 * t] = ((uint64_t)i << (id_bits + 11)) | (inv << id_bits) | j;
+          edges[2 * t + 1] = ((uint64_t)j << (id_bits + 11)) | (inv << id_bits) | i;
         }
       }
     }

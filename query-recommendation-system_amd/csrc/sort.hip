@@ -1031,7 +1031,10 @@ __global__ __launch_bounds__(FIN_THREADS, 8) void bucket_finish_kernel(const uin
 // of the part, once -- a key with any number of copies up to the region's size is no special case any more.
 // Output ranges are reserved on the same device cursor as the small parts'.
 constexpr int FIN_BIG_GRID = 256;
-constexpr int FIN_BIG_FACTOR = 3;      // a part's region holds this many LDS images
+#ifndef QR_FIN_BIG_FACTOR
+#define QR_FIN_BIG_FACTOR 3
+#endif
+constexpr int FIN_BIG_FACTOR = QR_FIN_BIG_FACTOR;  // a part's region holds this many LDS images
 constexpr uint32_t FIN_BIG_LIST = 65536;  // listed parts per call; beyond: overflow flag (general path)
 __global__ __launch_bounds__(FIN_THREADS) void bucket_finish_big_kernel(
     const uint64_t *__restrict__ keys, const uint32_t *__restrict__ ids, const uint32_t *__restrict__ counts, uint32_t cap,
