@@ -60,7 +60,7 @@ def parse():
                          "serialise back-to-back launches and cost ~10 %% of a step when recorded on all of them)")
     ap.add_argument("--exchange", default="all_to_all", choices=["all_to_all", "all_gather"],
                     help="bucket-id exchange of the sharded path (N > 1)")
-    ap.add_argument("--sig-exchange", default="auto", choices=["auto", "fetch", "all_gather", "recompute"])
+    ap.add_argument("--sig-exchange", default="auto", choices=["auto", "fetch", "sets", "all_gather", "recompute"])
     ap.add_argument("--force-dist", action="store_true", help="run the sharded driver even with one rank (testing)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-gpu: rehearse the N > 1 code path with all ranks on ONE GPU (testing; the "

@@ -39,9 +39,14 @@ With `sig_exchange` = "recompute" (answer sets replicated instead of signatures 
   2. -- no bucket-id exchange: the keys of the owned bands are read in place from the replicated
      [rank][band][queries] key buffer -- and no step 5: every row is local.  Steps 3, 4, 6, 7 as above.
 
+With `sig_exchange` = "sets": steps 1 - 4 and 6 - 7 as in "fetch", the answer-set gather of step 0 runs in the
+background from the start of the step, and at step 5 the rank computes the signatures of exactly the remote queries
+its pairs touch from the replicated answer sets (one MinHash launch; no requests, no rows on the wire).
+
 "auto" (default) = "recompute" for 2 to 4 ranks -- few ranks = few xGMI links, and everything a rank sends to one
 peer crosses ONE of them: 64 B of answer set per query against 256 B of signature row per scored pair plus 8 B of
-bucket id per band -- and "fetch" otherwise (one rank; five ranks and more, with seven links to spread over).
+bucket id per band -- "sets" from five ranks on (seven links to spread the bucket ids over; the rows of "fetch" would
+be 70 % of a rank's incoming bytes), "fetch" for one rank.
 
 Host round trips per step: the emitted-pair count, one per size exchange (pairs, row requests, edges),
 the unique-pair count and the top-K count.  Everything else is a libqrlsh kernel or a collective.
@@ -66,8 +71,9 @@ class HipBackend:
     def __init__(self):
         self.stats = {}   # which paths the kernels took (bucket_path, dedup_path, group_bits, part_bits)
 
-    def minhash(self, offsets, rows, table, b, out=None, validate=None):
-        return ops.minhash(offsets, rows, table, b=b, want_norm=True, compact=ops.can_compact(table),
+    def minhash(self, offsets, rows, table, b, out=None, validate=None, keys=True):
+        """(sig, norm2, band keys | None when keys is False)"""
+        return ops.minhash(offsets, rows, table, b=b if keys else None, want_norm=True, compact=ops.can_compact(table),
                            validate=self.validate if validate is None else validate, out=out)
 
     def sig_dtype(self, table):
@@ -278,6 +284,53 @@ class _Phases:
             self.sink["ms:" + name] = self.sink.get("ms:" + name, 0.0) + a.elapsed_time(e)
 
 
+def _gather_answer_sets(offsets, rows, table, nql, world, group, ph):
+    """asynchronous all-gather (second communicator) of every shard's answer sets: row ids padded to the largest
+    shard + the nql + 1 offsets.  On the wire the row ids are 16-bit words when the table has at most 65536 rows and
+    the offsets 32-bit ones (a shard holds fewer than 2^31 row ids): 34 instead of 72 bytes per query of mean size
+    16.  -> (rows [world, max_nnz], offsets [world, nql + 1], narrow, small_off, handle, handle)"""
+    dev = offsets.device
+    cnt = torch.empty((world,), dtype=torch.int64, device=dev)
+    _all_gather(cnt, torch.tensor([rows.numel()], dtype=torch.int64, device=dev), group)
+    max_nnz = max(1, int(cnt.max().item()))
+    rows_pad = rows if rows.numel() == max_nnz else torch.cat([rows, rows.new_zeros(max_nnz - rows.numel())])
+    bg = background_group(group)
+    narrow = table.D <= 65536
+    small_off = max_nnz < (1 << 31)
+    rows_w = rows_pad.to(torch.int16) if narrow else rows_pad
+    off_w = offsets.to(torch.int32) if small_off else offsets
+    ra_w = torch.empty((world, max_nnz), dtype=rows_w.dtype, device=dev)
+    oa_w = torch.empty((world, nql + 1), dtype=off_w.dtype, device=dev)
+    h_r = _all_gather(ra_w, rows_w.view(1, -1), bg, async_op=True)
+    h_o = _all_gather(oa_w, off_w.view(1, -1), bg, async_op=True)
+    ph.sent("0_answer_sets", (rows_w.numel() * rows_w.element_size() + off_w.numel() * off_w.element_size()) * (world - 1))
+    return ra_w, oa_w, narrow, small_off, h_r, h_o
+
+
+def _sets_of(need, ra_w, oa_w, nql, narrow):
+    """CSR (offsets int64 [n + 1], rows int32) of the answer sets of the global query ids `need`, taken out of the
+    replicated per-shard arrays of _gather_answer_sets (device-agnostic tensor indexing; one read-back: the number
+    of row ids)"""
+    n = need.numel()
+    max_nnz = ra_w.shape[1]
+    g = torch.div(need, nql, rounding_mode="floor")
+    base = g * (nql + 1) + (need - g * nql)
+    oflat = oa_w.view(-1)
+    start = oflat[base].to(torch.int64)
+    lens = oflat[base + 1].to(torch.int64) - start
+    off_b = torch.zeros((n + 1,), dtype=torch.int64, device=need.device)
+    torch.cumsum(lens, dim=0, out=off_b[1:])
+    tot = int(off_b[-1].item()) if n else 0
+    if tot == 0:
+        return off_b, torch.empty((0,), dtype=torch.int32, device=need.device)
+    idx = torch.repeat_interleave(g * max_nnz + start - off_b[:-1], lens, output_size=tot) + \
+        torch.arange(tot, dtype=torch.int64, device=need.device)
+    rows_b = ra_w.view(-1)[idx].to(torch.int32)
+    if narrow:
+        rows_b &= 0xFFFF
+    return off_b, rows_b
+
+
 def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="all_to_all", backend=None,
                                group=None, wide_ids=None, sig_exchange="auto", phases=None, local_dedup=None):
     """Hot path for this rank's query shard (the queries shard_range(nq_total, world, rank) names);
@@ -303,8 +356,8 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
         raise AssertionError("signature length %d not divisible by b=%d" % (P, b))
     if exchange not in ("all_to_all", "all_gather"):
         raise ValueError("exchange must be 'all_to_all' or 'all_gather'")
-    if sig_exchange not in ("auto", "fetch", "all_gather", "recompute"):
-        raise ValueError("sig_exchange must be 'auto', 'fetch', 'all_gather' or 'recompute'")
+    if sig_exchange not in ("auto", "fetch", "all_gather", "recompute", "sets"):
+        raise ValueError("sig_exchange must be 'auto', 'fetch', 'sets', 'all_gather' or 'recompute'")
     r = P // b
     ib = ops.id_bits_for(nids)
     wide = ops.wide_ids(ib) if wide_ids is None else wide_ids
@@ -316,30 +369,16 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
         # few ranks = few links, and everything a rank sends to one peer crosses ONE of them: up to four ranks the
         # answer sets are replicated instead (64 B per query, against 256 B of signature row per scored pair plus
         # 8 B per band of bucket ids) and every rank computes all signatures; beyond, shards stay shards
-        sig_exchange = "recompute" if 2 <= world <= 4 else "fetch"
+        # (... and from five ranks on the answer sets are still replicated -- in the background, 34 B per query -- but
+        # only the signatures a rank's pairs need are computed from them: no row fetch)
+        sig_exchange = "recompute" if 2 <= world <= 4 else ("sets" if world > 4 else "fetch")
     ranges = band_owner_ranges(b, world)
     lo, hi = ranges[rank]
     nb = hi - lo
     keys_all = None
     if sig_exchange == "recompute" and world > 1:
         # 0. answer sets of every shard: the offsets (nql + 1 each) and the row ids, padded to the largest shard
-        cnt = torch.empty((world,), dtype=torch.int64, device=dev)
-        _all_gather(cnt, torch.tensor([rows.numel()], dtype=torch.int64, device=dev), group)
-        max_nnz = max(1, int(cnt.max().item()))
-        rows_pad = rows if rows.numel() == max_nnz else torch.cat([rows, rows.new_zeros(max_nnz - rows.numel())])
-        bg = background_group(group)
-        # on the wire the row ids are 16-bit words when the table has at most 65536 rows and the offsets 32-bit ones
-        # (a shard holds fewer than 2^31 row ids): 34 instead of 72 bytes per query of mean size 16 -- this gather is
-        # what a two-rank step waits for longest (one xGMI link)
-        narrow = table.D <= 65536
-        small_off = max_nnz < (1 << 31)
-        rows_w = rows_pad.to(torch.int16) if narrow else rows_pad
-        off_w = offsets.to(torch.int32) if small_off else offsets
-        ra_w = torch.empty((world, max_nnz), dtype=rows_w.dtype, device=dev)
-        oa_w = torch.empty((world, nql + 1), dtype=off_w.dtype, device=dev)
-        h_r = _all_gather(ra_w, rows_w.view(1, -1), bg, async_op=True)
-        h_o = _all_gather(oa_w, off_w.view(1, -1), bg, async_op=True)
-        ph.sent("0_answer_sets", (rows_w.numel() * rows_w.element_size() + off_w.numel() * off_w.element_size()) * (world - 1))
+        ra_w, oa_w, narrow, small_off, h_r, h_o = _gather_answer_sets(offsets, rows, table, nql, world, group, ph)
         # 1. signatures of ALL queries, own shard first (it runs beside the gather); every block goes straight to
         #    its place in the replicated tables when the row blocks keep the kernel's 16-byte alignment
         sdt = be.sig_dtype(table)
@@ -367,11 +406,15 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
                 oa_g = oa_w[g].to(torch.int64) if small_off else oa_w[g]
                 shard_signatures(g, oa_g, ra_g, False)      # validated by their owner
                 del ra_g, oa_g
-        del ra_w, oa_w, rows_pad, rows_w, off_w
+        del ra_w, oa_w
         sig, norm2 = sa[q0:q0 + nql], na[q0:q0 + nql]
         keys = None
         stats["bucket_id_exchange"] = "none (answer sets replicated)"
     else:
+        sets = None
+        if sig_exchange == "sets" and world > 1:
+            # 0'. the same gather, in the background: what it brings is first needed at step 5
+            sets = _gather_answer_sets(offsets, rows, table, nql, world, group, ph)
         # 1. local signatures
         sig, norm2, keys = be.minhash(offsets, rows, table, b)
     ph.done("1_minhash")
@@ -454,6 +497,23 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
     elif world == 1:
         score_sig, score_norm, local_pairs = sig, norm2, pairs
         stats["remote_rows_fetched"] = 0
+    elif sig_exchange == "sets":
+        # the remote queries this rank's pairs touch: their answer sets are here already (step 0'), their signatures
+        # are computed now -- one MinHash over exactly the rows a fetch would have asked the owners for
+        ra_w, oa_w, narrow, _, h_r, h_o = sets
+        rid = be.remote_ids(pairs, q0, nql, nids, world)
+        need = be.remote_id_list(rid, int(rid.bounds[-1].item()))
+        h_r.wait()
+        h_o.wait()
+        off_b, rows_b = _sets_of(need, ra_w, oa_w, nql, narrow)
+        if need.numel():
+            sig_b, norm_b, _ = be.minhash(off_b, rows_b, table, b, validate=False, keys=False)
+        else:
+            sig_b, norm_b = sig[:0], norm2[:0]
+        stats["remote_signatures_computed"] = int(need.numel())
+        score_sig, score_norm = sig, norm2
+        local_pairs = be.remap_pairs(pairs, rid)
+        del rid, need, off_b, rows_b, ra_w, oa_w, sets
     else:
         rid = be.remote_ids(pairs, q0, nql, nids, world)
         ssz, rsz = _exchange_sizes(rid.bounds, group)                # ids I request / ids requested from me

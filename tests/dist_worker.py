@@ -36,7 +36,7 @@ class OracleBackend:
     def emit_pairs_bands(self, keys_all, lo, hi, r):
         return self.emit_pairs(qdist._band_major(keys_all, lo, hi), r)
 
-    def minhash(self, offsets, rows, table, b, out=None, validate=None):
+    def minhash(self, offsets, rows, table, b, out=None, validate=None, keys=True):
         sig = O.minhash(np.ascontiguousarray(offsets.numpy()), np.ascontiguousarray(rows.numpy()), table.perms)
         P = sig.shape[1]
         if P // b <= 4:

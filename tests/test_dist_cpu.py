@@ -35,6 +35,9 @@ def _run(tmp_path, world, nq, D, P, b, mode, port, extra=()):
                                                   (3, "all_to_all", 8, ("sig=recompute",), 601),    # no bucket-id / row exchange
                                                   (4, "all_to_all", 8, (), 598),                    # (auto up to 4 ranks)
                                                   (2, "all_to_all", 4, ("wide", "sig=recompute"), 599),
+                                                  (3, "all_to_all", 8, ("sig=sets",), 601),         # replicated sets, signatures on demand
+                                                  (5, "all_gather", 8, (), 603),                    # (auto from five ranks)
+                                                  (8, "all_to_all", 32, ("sig=sets",), 1001),
                                                   (8, "all_to_all", 8, ("sig=fetch",), 603),        # the driver's N = 8:
                                                   (8, "all_to_all", 32, ("sig=fetch",), 1001),      # one band / four bands per rank
                                                   (2, "all_to_all", 4, ("wide", "sig=fetch"), 600),

@@ -686,6 +686,8 @@ def _check_sharded_against(outs, res, nq, world):
                                                             (4, "all_gather", "gloo", "fetch", 40000),
                                                             (3, "all_to_all", "gloo", "fetch", 40001),   # padded last shard
                                                             (2, "all_to_all", "gloo", "all_gather", 39999),
+                                                            (3, "all_to_all", "gloo", "sets", 40001),
+                                                            (5, "all_to_all", "gloo", "auto", 40003),    # auto = sets
                                                             (3, "all_to_all", "gloo", "recompute", 40001),
                                                             (2, "all_to_all", "gloo", "recompute", 30001)])
 def test_sharded_driver_on_gpu_equals_single_gpu(tmp_path, world, mode, backend, sig_mode, nq):
@@ -736,13 +738,14 @@ def test_sharded_config3_shape_four_ranks(tmp_path):
 
 
 def test_sharded_config3_shape_five_ranks_all_gather_of_bucket_ids(tmp_path):
-    """configs[3] with the exchange BASELINE's north_star names -- an ALL-GATHER of the bucket ids -- and the row
-    fetch ("fetch": what `auto` picks for the 8-GPU run), at the largest rank count this box allows: a GPU box admits
+    """configs[3] with the exchange BASELINE's north_star names -- an ALL-GATHER of the bucket ids -- and the
+    signatures of remote queries computed from the replicated answer sets ("sets": what `auto` picks for the 8-GPU run;
+    the four-rank test above covers the row fetch), at the largest rank count this box allows: a GPU box admits
     at most 6 processes on its card: five ranks + this process (the 8-rank layout -- 4 bands per rank, shards of
     1.25 M -- is covered on the CPU by tests/test_dist_cpu.py at world 8 and, rank by rank at configs[4]'s size, by
     test_config4_rank_slice below).  32 bands over 5 ranks is an UNEVEN band split (7, 7, 7, 7, 4)."""
     nq, D, P, b, world = 10_000_000, 32768, 128, 32, 5
-    outs = _run_dist_gpu(tmp_path, world, nq, D, P, b, "all_gather", "gloo", 29631, "fetch")
+    outs = _run_dist_gpu(tmp_path, world, nq, D, P, b, "all_gather", "gloo", 29631, "sets")
     K = pipeline.max_candidates(nq)
     off, rows = qrlsh.synth_csr(nq, D, seed=0, device=DEV)
     res = pipeline.query_similarities(off, rows, ops.perm_table(ops.legacy_permutations(P, D, seed=42), DEV), b, K)
@@ -751,7 +754,7 @@ def test_sharded_config3_shape_five_ranks_all_gather_of_bucket_ids(tmp_path):
     sizes = [len(o["pairs"]) for o in outs]
     assert max(sizes) < 1.05 * sum(sizes) / world
     for o in outs:
-        assert str(o["sig_exchange"]) == "fetch"
+        assert str(o["sig_exchange"]) == "sets"
     del res
     torch.cuda.empty_cache()
 

@@ -8,6 +8,6 @@ table = ops.perm_table(ops.legacy_permutations(128, D, seed=42), "cuda")
 K = pipeline.max_candidates(nq)
 for _ in range(5): res = pipeline.query_similarities(off, rows, table, 32, K, validate=False)
 torch.cuda.synchronize(); t=time.perf_counter()
-n = 40 if nq <= 2_000_000 else 15
+n = 100 if nq <= 2_000_000 else 60
 for _ in range(n): res = pipeline.query_similarities(off, rows, table, 32, K, validate=False)
 torch.cuda.synchronize(); print("nq", nq, "OVERLAP", os.environ.get("QRLSH_OVERLAP"), "GROUPS", os.environ.get("QRLSH_EMIT_GROUPS"), "ms/step %.3f" % ((time.perf_counter()-t)/n*1e3), res.pairs.numel())
