@@ -864,6 +864,37 @@ def test_config4_rank_slice():
     torch.cuda.empty_cache()
 
 
+def test_bench_starts_its_own_ranks_when_no_launcher_did():
+    """the driver's scaling command is the plain `python bench.py --gpus N ...`: with WORLD_SIZE unset bench.py must
+    start the N ranks itself (as child processes, before anything touches the GPU), relay rank 0's ONE JSON line and
+    return the launcher's code.  Rehearsed here with two gloo ranks sharing this GPU on a small workload: the line is
+    well-formed, names two ranks and carries the same candidate / top-K counts as the one-GPU pipeline."""
+    import json
+    import subprocess
+    import sys as _sys
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    nq = 200_000
+    p = subprocess.run([_sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--share-gpu",
+                        "--steps", "2", "--warmup", "1", "--nq-total", str(nq), "--no-secondary"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                      # ONE JSON line on stdout, everything else on stderr
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "signatures/s"
+    assert d["config"]["queries_total"] == nq and d["config"]["queries_per_rank"] == nq // 2
+    assert d["config"]["signature_exchange"] == "recompute" and d["value"] > 0
+    assert set(d["phases_rank0"]["bytes_sent"]) == {"0_answer_sets", "4_pairs", "6_edges"}
+    K = pipeline.max_candidates(nq)
+    off, rows = qrlsh.synth_csr(nq, 32768, seed=0, device=DEV)
+    res = pipeline.query_similarities(off, rows, ops.perm_table(ops.legacy_permutations(128, 32768, seed=42), DEV), 32, K)
+    assert (d["unique_pairs"], d["kept_edges"], d["emitted_pairs"]) == (res.pairs.numel(), res.src.numel(),
+                                                                       res.stats["emitted_pairs"])
+
+
 def test_sharded_driver_wide_ids_beyond_2_pow_26(tmp_path):
     """config-5-sized id space through the SHARDED driver on the device: nq_total > 2^26 (key + payload
     edges, re-based to 64-bit local keys on arrival), more than 2^24 records per owned band (32-bit ids
