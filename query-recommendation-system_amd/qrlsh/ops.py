@@ -5,7 +5,6 @@ raw pointers and the current HIP stream to libqrlsh, and returns tensors.  64-bi
 words (band keys, pairs, edge keys) are carried in torch.int64 tensors (bit patterns).
 """
 import ctypes
-import os
 
 import numpy as np
 import torch
@@ -412,9 +411,6 @@ def part_bits_for(n):
     """T = bits of the hash partition of the fast bucket path: parts of <= ~4400 records on
     average (the LDS image holds 6144; the room above the mean is for popular keys -- with parts of ~4900
     on average the 10 M-query bench workload overflows a part), at least 8, at most 16."""
-    import os
-    if os.environ.get("QRLSH_PART_BITS"):          # development override (image-size experiments)
-        return int(os.environ["QRLSH_PART_BITS"])
     t = 8
     while t < 16 and n > 4400 * (1 << t):
         t += 1
@@ -449,7 +445,7 @@ def emit_pairs_fast(keys, r, part_bits=None, one_pass=True, capacity=None, chunk
         layout = (0, 0, 0)
     dev = keys.device
     T = part_bits if part_bits is not None else part_bits_for(nq)
-    if nq > 6144 * (1 << T) and not os.environ.get("QRLSH_PART_BITS"):
+    if nq > 6144 * (1 << T):
         return None  # cannot fit even with the finest partition
     words = lib.qrlsh_bucket_part_words(nq, b, T) if one_pass else b * nq
     pk = torch.empty((words,), dtype=torch.int64, device=dev)
