@@ -778,6 +778,16 @@ def test_config4_rank_slice():
     assert (nql, nb, n_real) == (12_500_000, 8, 12_500_000)
     perms = ops.legacy_permutations(P, D, seed=42)
     table = ops.perm_table(perms, DEV)
+    import time
+    stage_ms = {}
+
+    def timed(label, fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        stage_ms[label] = stage_ms.get(label, 0.0) + (time.perf_counter() - t0) * 1e3
+        return out
     recv = torch.empty((world, nb, nql), dtype=torch.int64, device=DEV)
     sig_all = torch.empty((nq, P), dtype=torch.int16, device=DEV)            # 51 GB: every rank's rows (288 GB HBM)
     norm_all = torch.empty((nq,), dtype=torch.int64, device=DEV)
@@ -786,6 +796,9 @@ def test_config4_rank_slice():
     for s_ in range(world):
         off, rows = qrlsh.synth_csr(nq, D, seed=0, q0=s_ * nql, nq_local=nql, device=DEV)
         blk = slice(s_ * nql, (s_ + 1) * nql)
+        if s_ == rank:
+            timed("1 MinHash of the rank's 12.5 M queries (P = 256)",
+                  lambda: ops.minhash(off, rows, table, b=b, compact=True, validate=False, out=(sig_all[blk], norm_all[blk], keys)))
         ops.minhash(off, rows, table, b=b, compact=True, validate=(s_ == rank), out=(sig_all[blk], norm_all[blk], keys))
         recv[s_].copy_(keys[lo:hi])
         if s_ in (0, world - 1):        # the first 100 000 signatures of the first / last shard against the oracle
@@ -798,18 +811,15 @@ def test_config4_rank_slice():
     del keys
     # 3. pairs of the owned bands over all ids, from the exchanged layout in place
     #    (the product call: the partition + LDS finish, or -- when a part overflows its LDS image -- the general sort path)
-    import time
     be = qdist.HipBackend()
-    torch.cuda.synchronize()
-    t_emit = time.perf_counter()
-    emitted = be.emit_pairs_chunked(recv.view(-1), world, nb, nql, r)
-    torch.cuda.synchronize()
-    t_emit = time.perf_counter() - t_emit
+    be.emit_pairs_chunked(recv.view(-1), world, nb, nql, r)          # (settles the pair-buffer size guess)
+    emitted = timed("3 partition + finish, 8 owned bands x 100 M ids", lambda: be.emit_pairs_chunked(recv.view(-1), world, nb, nql, r))
+    t_emit = stage_ms["3 partition + finish, 8 owned bands x 100 M ids"] / 1e3
     assert ops.part_bits_for(nq) == 15
     bucket_path = be.stats["bucket_path"]
     n_emitted = emitted.numel()
     # 4. hosting split: what this rank keeps of its own emission
-    grouped, _ = ops.sort_u64(emitted, None, host_shard=nql)
+    grouped, _ = timed("4a grouping of the emitted pairs by scoring rank", lambda: ops.sort_u64(emitted, None, host_shard=nql))
     del emitted
     bounds = ops.owner_bounds(grouped, -1, nql, world).tolist()
     shares = np.diff(bounds)
@@ -817,7 +827,8 @@ def test_config4_rank_slice():
     mine = grouped[bounds[rank]:bounds[rank + 1]].clone()
     del grouped
     stats = {}
-    pairs = ops.unique_pairs(mine, nq, stats, words_per_query=mine.numel() / (2 * nql))
+    pairs = timed("4b de-duplication of the pairs hosted here (from this rank's bands only: 1/8 of what arrives)",
+                  lambda: ops.unique_pairs(mine, nq, stats, words_per_query=mine.numel() / (2 * nql)))
     del mine
     assert stats["dedup_path"] == "regions-in-lds" and stats["group_bits"] == 5
     hp = u64(pairs)
@@ -832,7 +843,7 @@ def test_config4_rank_slice():
     assert np.array_equal(hp, opairs[pair_host(opairs, nql) == rank])
     del opairs
     # 5. the rows the pairs need: ids requested from their owners (here: gathered out of the full table)
-    rid = ops.remote_ids(pairs, q0, nql, nq, world)
+    rid = timed("5a remote-id set of the hosted pairs", lambda: ops.remote_ids(pairs, q0, nql, nq, world))
     sizes = rid.bounds.tolist()
     need = ops.remote_id_list(rid, sizes[-1])
     hn = need.cpu().numpy()
@@ -841,7 +852,8 @@ def test_config4_rank_slice():
     assert np.array_equal(hn, touched[(touched < q0) | (touched >= q0 + nql)])
     rows_b, norms_b = ops.gather_rows(sig_all, norm_all, need, 0)
     local = ops.remap_pairs_ids(pairs, rid)
-    milli = ops.score_pairs_split(sig_all[q0:q0 + nql], norm_all[q0:q0 + nql], rows_b, norms_b, local)
+    milli = timed("6 scoring of the hosted pairs (two-piece row table)",
+                  lambda: ops.score_pairs_split(sig_all[q0:q0 + nql], norm_all[q0:q0 + nql], rows_b, norms_b, local))
     whole, _, _ = ops.score_pairs(sig_all, norm_all, pairs)            # the same pairs against the one-piece table
     assert torch.equal(milli, whole)
     del whole, rows_b, norms_b, local
@@ -860,6 +872,8 @@ def test_config4_rank_slice():
     assert ek.numel() == 2 * pairs.numel() and ed.numel() == 2 * pairs.numel()
     print("configs[4] rank slice: bucket path %s (%.1f ms for the 8 owned bands x 100 M ids), emitted %d, hosted here %d "
           "unique, remote rows %d" % (bucket_path, t_emit * 1e3, n_emitted, len(hp), len(hn)))
+    for k_ in sorted(stage_ms):
+        print("configs[4] rank slice:   %-100s %8.1f ms" % (k_, stage_ms[k_]))
     del sig_all, norm_all, recv
     torch.cuda.empty_cache()
 
