@@ -81,6 +81,26 @@ def test_sharded_equals_single_process(tmp_path, world, mode, b, extra, nq):
     assert max(sizes) <= 2.0 * sum(sizes) / world + 16               # the coin splits the pairs about evenly
 
 
+@pytest.mark.parametrize("world,extra", [(2, ("sig=recompute",)), (3, ("sig=sets",))])
+def test_replicated_answer_sets_with_more_than_65536_table_rows(tmp_path, world, extra):
+    """the answer-set gather of the recompute / sets modes sends 16-bit row ids only while the table has at most 65536
+    rows; beyond (here D = 70 000: int32 permutation table, int32 signature rows, int16 wrap in the band keys) the
+    ids travel as 32-bit words -- same results as one process"""
+    nq, D, P, b = 300, 70000, 32, 8
+    outs = _run(tmp_path, world, nq, D, P, b, "all_to_all", 29700 + world, extra)
+    K = O.max_candidates(nq)
+    off, rows = O.synth_csr(nq, D, seed=3, cluster=4, mean=6.0)
+    assert rows.max() > 65535
+    ref = O.query_similarities(off, rows, D, P, b, K, 42)
+    assert np.array_equal(np.concatenate([o["sig"] for o in outs]), ref["sig"])
+    pairs = np.concatenate([o["pairs"] for o in outs]).view(np.uint64)
+    order = np.argsort(pairs, kind="stable")
+    assert np.array_equal(pairs[order], ref["pairs"])
+    assert np.array_equal(np.concatenate([o["milli"] for o in outs])[order], ref["milli"])
+    for k in ("src", "dst", "val"):
+        assert np.array_equal(np.concatenate([o[k] for o in outs]), ref[k])
+
+
 def test_shard_ranges_tile_the_queries():
     import qrlsh.dist as qd
     for nq in (1, 7, 600, 601, 10_000_000):
