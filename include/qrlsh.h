@@ -400,6 +400,21 @@ int qrlsh_predict(const int32_t *ratings, int64_t nu, int64_t nq, const int64_t 
 int qrlsh_center_rows(const int32_t *ratings, int64_t nu, int64_t nq, int64_t nq_stride, int32_t *out,
                       void *stream);
 
+/* ---- multi-GPU, "sets" mode: answer sets of chosen queries out of the replicated per-shard CSR arrays ------------
+ * Every rank holds every shard's answer sets as an all-gather delivered them: offs[world][nql + 1] (off_bytes = 4 or 8)
+ * and rows[world][max_nnz] (row_bytes = 2: unsigned 16-bit row ids, tables of at most 65536 rows; or 4), shard g =
+ * queries [g * nql, (g + 1) * nql).  For the n global query ids in `ids` (the remote queries a rank's pairs touch:
+ * qrlsh_idset_list): _count writes offsets_out[n + 1] = exclusive scan of their set sizes ([n] = number of row ids:
+ * the caller reads it back to allocate), _fill the row ids as int32 -- the CSR qrlsh_minhash takes.  Replaces a row
+ * fetch from the owners: no signature row crosses a link.  Workspace: qrlsh_gather_sets_workspace_bytes(n). */
+size_t qrlsh_gather_sets_workspace_bytes(int64_t n);
+int qrlsh_gather_sets_count(const uint64_t *ids, int64_t n, const void *offs, int32_t off_bytes, int64_t nql,
+                            int64_t world, uint64_t *offsets_out, void *workspace, size_t workspace_bytes,
+                            void *stream);
+int qrlsh_gather_sets_fill(const uint64_t *ids, int64_t n, const void *offs, int32_t off_bytes, const void *rows,
+                           int32_t row_bytes, int64_t nql, int64_t max_nnz, const uint64_t *offsets,
+                           int32_t *rows_out, void *stream);
+
 /* ---- synthetic answer sets (bench / test input) ---------------
  * Bit-identical twin of oracle/qr_oracle.c:qro_synth_*: a pure function of (seed, q).
  * sizes: sizes_out[i] = |A(q0 + i)|; fill: rows at offsets[i] (offsets = exclusive scan).

@@ -6,6 +6,8 @@
 // fetch), pairs re-indexed into its row table [local rows | fetched rows], the rows other ranks ask for,
 // and edge keys re-based to its own id range.  All of that is index work on the device -- no host
 // round trip beyond the sizes an all-to-all needs.
+#include <type_traits>
+
 #include "common.h"
 
 // ---- id set: a bitmap over the (padded) global id space + its rank structure ----------------------------
@@ -218,5 +220,92 @@ QRLSH_EXPORT int qrlsh_edges_localize(const uint64_t *edges, const uint32_t *edg
   QR_LAUNCH("edges_localize", edges_localize_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0,
             static_cast<hipStream_t>(stream), edges, edge_dst, n, id_bits, (uint64_t)q0, out);
   QR_LAUNCH_CHECK("qrlsh_edges_localize");
+  return QRLSH_OK;
+}
+
+// ---- answer sets of chosen queries out of the replicated per-shard CSR arrays ("sets" mode of qrlsh/dist.py) ------
+// Every rank holds every shard's answer sets as they came off the wire: offs[world][nql + 1] (32- or 64-bit words)
+// and rows[world][max_nnz] (16-bit words when the table has at most 65536 rows, else 32-bit), shard g = queries
+// [g * nql, (g + 1) * nql).  A scoring rank needs the sets of the remote queries its pairs touch, as one CSR the
+// MinHash kernel can take: count (lengths -> exclusive scan, total read back by the caller for the allocation), fill.
+template <typename OffT>
+__global__ __launch_bounds__(256) void sets_len_kernel(const uint64_t *__restrict__ ids, int64_t n,
+                                                       const OffT *__restrict__ offs, int64_t nql,
+                                                       uint64_t *__restrict__ lens) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t > n) return;
+  uint64_t len = 0;
+  if (t < n) {
+    const uint64_t q = ids[t], g = q / (uint64_t)nql, l = q - g * (uint64_t)nql;
+    const OffT *o = offs + g * (uint64_t)(nql + 1) + l;
+    len = (uint64_t)(o[1] - o[0]);
+  }
+  lens[t] = len;  // one word past the end: the scan leaves the total there
+}
+
+// 16 lanes per query copy its row ids (consecutive lanes = consecutive words)
+template <typename OffT, typename RowT>
+__global__ __launch_bounds__(256) void sets_fill_kernel(const uint64_t *__restrict__ ids, int64_t n,
+                                                        const OffT *__restrict__ offs, const RowT *__restrict__ rows,
+                                                        int64_t nql, int64_t max_nnz,
+                                                        const uint64_t *__restrict__ out_off,
+                                                        int32_t *__restrict__ rows_out) {
+  const int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const int lig = threadIdx.x & 15;
+  if (t >= n) return;
+  const uint64_t q = ids[t], g = q / (uint64_t)nql, l = q - g * (uint64_t)nql;
+  const uint64_t s0 = (uint64_t)offs[g * (uint64_t)(nql + 1) + l];
+  const uint64_t o0 = out_off[t], len = out_off[t + 1] - o0;
+  const RowT *src = rows + g * (uint64_t)max_nnz + s0;
+  for (uint64_t k = lig; k < len; k += 16) rows_out[o0 + k] = (int32_t)(uint32_t)(typename std::make_unsigned<RowT>::type)src[k];
+}
+
+QRLSH_EXPORT size_t qrlsh_gather_sets_workspace_bytes(int64_t n) {
+  return (size_t)(ceil_div64((n > 0 ? n : 0) + 1, SCANL_CHUNK) + 2) * sizeof(uint64_t);
+}
+
+// offsets_out[n + 1] (uint64): exclusive scan of the chosen queries' set sizes, [n] = the number of row ids
+QRLSH_EXPORT int qrlsh_gather_sets_count(const uint64_t *ids, int64_t n, const void *offs, int32_t off_bytes, int64_t nql,
+                                         int64_t world, uint64_t *offsets_out, void *workspace, size_t workspace_bytes,
+                                         void *stream) {
+  QR_CHECK_ARG(n >= 0 && nql > 0 && world > 0 && (off_bytes == 4 || off_bytes == 8) && offsets_out && workspace,
+               "qrlsh_gather_sets_count: bad arguments");
+  QR_CHECK_ARG(n == 0 || (ids && offs), "qrlsh_gather_sets_count: null pointer");
+  if (workspace_bytes < qrlsh_gather_sets_workspace_bytes(n)) {
+    qrlsh_set_error("qrlsh_gather_sets_count: workspace %zu < %zu bytes", workspace_bytes, qrlsh_gather_sets_workspace_bytes(n));
+    return QRLSH_EWORKSPACE;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)ceil_div64(n + 1, 256)), block(256);
+  if (off_bytes == 4)
+    QR_LAUNCH("sets_len", (sets_len_kernel<int32_t>), grid, block, 0, st, ids, n, static_cast<const int32_t *>(offs), nql,
+              offsets_out);
+  else
+    QR_LAUNCH("sets_len", (sets_len_kernel<int64_t>), grid, block, 0, st, ids, n, static_cast<const int64_t *>(offs), nql,
+              offsets_out);
+  uint64_t *sums = static_cast<uint64_t *>(workspace);
+  qr_scan_u64(offsets_out, n + 1, sums, sums + 1, st);   // (offsets_out[n] = the total; sums[0] receives it too)
+  QR_LAUNCH_CHECK("qrlsh_gather_sets_count");
+  return QRLSH_OK;
+}
+
+QRLSH_EXPORT int qrlsh_gather_sets_fill(const uint64_t *ids, int64_t n, const void *offs, int32_t off_bytes,
+                                        const void *rows, int32_t row_bytes, int64_t nql, int64_t max_nnz,
+                                        const uint64_t *offsets, int32_t *rows_out, void *stream) {
+  QR_CHECK_ARG(n >= 0 && nql > 0 && max_nnz >= 0 && (off_bytes == 4 || off_bytes == 8) && (row_bytes == 2 || row_bytes == 4),
+               "qrlsh_gather_sets_fill: bad arguments");
+  if (n == 0) return QRLSH_OK;
+  QR_CHECK_ARG(ids && offs && rows && offsets && rows_out, "qrlsh_gather_sets_fill: null pointer");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)ceil_div64(n * 16, 256)), block(256);
+#define QR_SETS_FILL(OT, RT)                                                                                          \
+  QR_LAUNCH("sets_fill", (sets_fill_kernel<OT, RT>), grid, block, 0, st, ids, n, static_cast<const OT *>(offs),       \
+            static_cast<const RT *>(rows), nql, max_nnz, offsets, rows_out)
+  if (off_bytes == 4 && row_bytes == 2) QR_SETS_FILL(int32_t, int16_t);
+  else if (off_bytes == 4) QR_SETS_FILL(int32_t, int32_t);
+  else if (row_bytes == 2) QR_SETS_FILL(int64_t, int16_t);
+  else QR_SETS_FILL(int64_t, int32_t);
+#undef QR_SETS_FILL
+  QR_LAUNCH_CHECK("qrlsh_gather_sets_fill");
   return QRLSH_OK;
 }

@@ -129,6 +129,10 @@ class HipBackend:
     def gather_rows(self, sig, norm2, ids, q0):
         return ops.gather_rows(sig, norm2, ids, q0)
 
+    def gather_sets(self, ids, offs_all, rows_all, nql):
+        """CSR of the answer sets of `ids` out of the replicated per-shard arrays (qrlsh_gather_sets_*)"""
+        return ops.gather_sets(ids, offs_all, rows_all, nql)
+
     def score(self, sig, norm2, sig_b, norm2_b, pairs):
         """milli of pairs whose halves index the row table [sig | sig_b]"""
         if sig_b is None:
@@ -307,30 +311,6 @@ def _gather_answer_sets(offsets, rows, table, nql, world, group, ph):
     return ra_w, oa_w, narrow, small_off, h_r, h_o
 
 
-def _sets_of(need, ra_w, oa_w, nql, narrow):
-    """CSR (offsets int64 [n + 1], rows int32) of the answer sets of the global query ids `need`, taken out of the
-    replicated per-shard arrays of _gather_answer_sets (device-agnostic tensor indexing; one read-back: the number
-    of row ids)"""
-    n = need.numel()
-    max_nnz = ra_w.shape[1]
-    g = torch.div(need, nql, rounding_mode="floor")
-    base = g * (nql + 1) + (need - g * nql)
-    oflat = oa_w.view(-1)
-    start = oflat[base].to(torch.int64)
-    lens = oflat[base + 1].to(torch.int64) - start
-    off_b = torch.zeros((n + 1,), dtype=torch.int64, device=need.device)
-    torch.cumsum(lens, dim=0, out=off_b[1:])
-    tot = int(off_b[-1].item()) if n else 0
-    if tot == 0:
-        return off_b, torch.empty((0,), dtype=torch.int32, device=need.device)
-    idx = torch.repeat_interleave(g * max_nnz + start - off_b[:-1], lens, output_size=tot) + \
-        torch.arange(tot, dtype=torch.int64, device=need.device)
-    rows_b = ra_w.view(-1)[idx].to(torch.int32)
-    if narrow:
-        rows_b &= 0xFFFF
-    return off_b, rows_b
-
-
 def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="all_to_all", backend=None,
                                group=None, wide_ids=None, sig_exchange="auto", phases=None, local_dedup=None):
     """Hot path for this rank's query shard (the queries shard_range(nq_total, world, rank) names);
@@ -505,7 +485,7 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
         need = be.remote_id_list(rid, int(rid.bounds[-1].item()))
         h_r.wait()
         h_o.wait()
-        off_b, rows_b = _sets_of(need, ra_w, oa_w, nql, narrow)
+        off_b, rows_b = be.gather_sets(need, oa_w, ra_w, nql)
         if need.numel():
             sig_b, norm_b, _ = be.minhash(off_b, rows_b, table, b, validate=False, keys=False)
         else:

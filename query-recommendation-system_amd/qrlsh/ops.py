@@ -628,6 +628,32 @@ def gather_rows(sig, norm2, ids, q0):
     return rows, norms
 
 
+def gather_sets(ids, offs_all, rows_all, nql):
+    """CSR (offsets int64 [n + 1], rows int32) of the answer sets of the global query ids `ids` (int64, ascending or
+    not) out of the replicated per-shard arrays: offs_all [world, nql + 1] int32 / int64, rows_all [world, max_nnz]
+    int16 (unsigned 16-bit row ids) / int32 (one read-back: the number of row ids)"""
+    lib = _lib.load()
+    _need(ids, torch.int64, "ids", 1)
+    if offs_all.dtype not in (torch.int32, torch.int64) or rows_all.dtype not in (torch.int16, torch.int32):
+        raise TypeError("offs_all must be int32 / int64, rows_all int16 / int32")
+    _need(offs_all, offs_all.dtype, "offs_all", 2)
+    _need(rows_all, rows_all.dtype, "rows_all", 2)
+    world, max_nnz = rows_all.shape
+    if tuple(offs_all.shape) != (world, nql + 1):
+        raise ValueError("offs_all must be [world, nql + 1]")
+    n, dev = ids.numel(), ids.device
+    off = torch.empty((n + 1,), dtype=torch.int64, device=dev)
+    ws = _ws(lib.qrlsh_gather_sets_workspace_bytes(n), dev)
+    _lib.check(lib.qrlsh_gather_sets_count(_ptr(ids), n, _ptr(offs_all), offs_all.element_size(), int(nql), world, _ptr(off),
+                                           _ptr(ws), ws.numel(), _stream()))
+    total = int(off[-1].item())
+    rows = torch.empty((total,), dtype=torch.int32, device=dev)
+    if total:
+        _lib.check(lib.qrlsh_gather_sets_fill(_ptr(ids), n, _ptr(offs_all), offs_all.element_size(), _ptr(rows_all),
+                                              rows_all.element_size(), int(nql), max_nnz, _ptr(off), _ptr(rows), _stream()))
+    return off, rows
+
+
 def score_pairs_split(sig, norm2, sig_b, norm2_b, pairs):
     """milli of pairs whose halves index the two-piece row table [sig | sig_b]"""
     lib = _lib.load()

@@ -91,6 +91,26 @@ class OracleBackend:
     def sort_unique(self, words, nids, words_per_query=None):
         return _t(np.unique(words.numpy().view(np.uint64)).view(np.int64))
 
+    def gather_sets(self, ids, offs_all, rows_all, nql):
+        """answer sets of `ids` out of the replicated per-shard arrays (tensor indexing twin of qrlsh_gather_sets_*)"""
+        n = ids.numel()
+        max_nnz = rows_all.shape[1]
+        g = torch.div(ids, nql, rounding_mode="floor")
+        base = g * (nql + 1) + (ids - g * nql)
+        oflat = offs_all.reshape(-1)
+        start = oflat[base].to(torch.int64)
+        lens = oflat[base + 1].to(torch.int64) - start
+        off_b = torch.zeros((n + 1,), dtype=torch.int64)
+        torch.cumsum(lens, dim=0, out=off_b[1:])
+        tot = int(off_b[-1])
+        if tot == 0:
+            return off_b, torch.empty((0,), dtype=torch.int32)
+        idx = torch.repeat_interleave(g * max_nnz + start - off_b[:-1], lens, output_size=tot) + torch.arange(tot, dtype=torch.int64)
+        rows_b = rows_all.reshape(-1)[idx].to(torch.int32)
+        if rows_all.dtype == torch.int16:
+            rows_b &= 0xFFFF
+        return off_b, rows_b
+
     def remote_ids(self, pairs, q0, nql, nids, world):
         p = pairs.numpy().view(np.uint64)
         ends = np.concatenate([(p >> np.uint64(32)), (p & np.uint64(0xFFFFFFFF))]).astype(np.int64)

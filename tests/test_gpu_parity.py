@@ -993,6 +993,37 @@ def test_multi_gpu_glue_kernels_match_numpy():
 
 
 # ---------------------------------------------------------------------------- fast bucket path
+def test_gather_sets_out_of_replicated_shards():
+    """qrlsh_gather_sets_* ("sets" mode of the sharded driver): the answer sets of chosen global query ids out of the
+    per-shard arrays as the all-gather leaves them -- 16- / 32-bit row ids, 32- / 64-bit offsets, padded shards --
+    equal the sets themselves"""
+    rng = np.random.default_rng(9)
+    world, nql, D = 5, 3001, 70000
+    offs, rows = [], []
+    for g in range(world):
+        lens = rng.integers(0, 40, size=nql)
+        if g == world - 1:
+            lens[-700:] = 0                               # padded tail of the last shard
+        o = np.concatenate(([0], np.cumsum(lens)))
+        offs.append(o)
+        rows.append(rng.integers(0, D, size=int(o[-1])))
+    max_nnz = max(len(r) for r in rows)
+    ids = np.sort(rng.choice(world * nql, size=4000, replace=False)).astype(np.int64)
+    want_off = np.concatenate(([0], np.cumsum([offs[q // nql][q % nql + 1] - offs[q // nql][q % nql] for q in ids])))
+    want_rows = np.concatenate([rows[q // nql][offs[q // nql][q % nql]:offs[q // nql][q % nql + 1]] for q in ids])
+    for odt, rdt in ((np.int32, np.int16), (np.int64, np.int32), (np.int32, np.int32)):
+        oa = np.stack(offs).astype(odt)
+        ra = np.zeros((world, max_nnz), dtype=np.int64)
+        for g in range(world):
+            ra[g, :len(rows[g])] = rows[g] if rdt == np.int32 else rows[g] % 65536
+        ra = ra.astype(np.uint16).view(np.int16) if rdt == np.int16 else ra.astype(np.int32)
+        off, got = ops.gather_sets(dev(ids), dev(oa), dev(ra), nql)
+        assert np.array_equal(off.cpu().numpy(), want_off)
+        assert np.array_equal(got.cpu().numpy(), want_rows if rdt == np.int32 else want_rows % 65536)
+    off, got = ops.gather_sets(dev(ids[:0]), dev(oa), dev(ra), nql)
+    assert off.tolist() == [0] and got.numel() == 0
+
+
 def test_fast_bucket_path_equals_general_path():
     rng = np.random.default_rng(11)
     for (nq, b, nkeys) in [(1, 2, 5), (50, 3, 7), (5000, 4, 900), (70000, 8, 20000), (300000, 2, 40)]:
