@@ -273,6 +273,10 @@ int qrlsh_topk_fill_based(const uint64_t *sorted_edges, const uint32_t *sorted_d
  * descending, neighbour id ascending; at most K of them are looked for) and, if fewer than K do, lands at that
  * rank of its query's output row.  count: *total_out = number of edges kept; fill writes the same (src, dst,
  * milli) COO qrlsh_topk_fill does.  nq = number of query ids; n < 2^31 pairs.
+  * pairs == NULL (and milli == NULL in _fill): the lists are made of the n reverse words alone, whatever scored them
+ * (the sharded driver: every directed edge a rank receives, re-based to its id range by qrlsh_edges_localize, IS
+ * such a word with src = one of its own queries; sorted on the src bits only); packed words then need
+ * src < 2^(53 - id_bits) instead of id_bits <= 26.
  */
 int qrlsh_score_pairs_rev(const void *sig, int32_t sig_dtype, const int64_t *norm2, int32_t P,
                           const uint64_t *pairs, int64_t n, int32_t *milli_out, uint64_t *rev_out, int32_t id_bits,

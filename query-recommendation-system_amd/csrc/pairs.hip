@@ -1081,8 +1081,8 @@ __device__ static inline int64_t edge_src(const uint64_t *__restrict__ a, int64_
 __global__ __launch_bounds__(256) void edge_bounds_kernel(const uint64_t *__restrict__ pairs,
                                                           const uint64_t *__restrict__ rev, int64_t n, int64_t nq,
                                                           int id_bits, int wide, uint32_t *__restrict__ fstart,
-                                                          uint32_t *__restrict__ rstart) {
-  const bool fwd = blockIdx.y == 0;
+                                                          uint32_t *__restrict__ rstart, int y0 = 0) {
+  const bool fwd = blockIdx.y + y0 == 0;  // (y0 = 1: reverse words only, no forward list)
   const uint64_t *a = fwd ? pairs : rev;
   uint32_t *start = fwd ? fstart : rstart;
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1099,8 +1099,8 @@ __global__ __launch_bounds__(256) void edge_bounds_kernel(const uint64_t *__rest
 __global__ __launch_bounds__(256) void edge_bounds_fix_kernel(const uint64_t *__restrict__ pairs,
                                                               const uint64_t *__restrict__ rev, int64_t n, int64_t nq,
                                                               int id_bits, int wide, uint32_t *__restrict__ fstart,
-                                                              uint32_t *__restrict__ rstart) {
-  const bool fwd = blockIdx.y == 0;
+                                                              uint32_t *__restrict__ rstart, int y0 = 0) {
+  const bool fwd = blockIdx.y + y0 == 0;
   const uint64_t *a = fwd ? pairs : rev;
   uint32_t *start = fwd ? fstart : rstart;
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1299,7 +1299,7 @@ __global__ __launch_bounds__(256) void topk_select_long_kernel(const uint64_t *_
                                                                const unsigned long long *__restrict__ nlists, int K,
                                                                int id_bits, int32_t *__restrict__ src_out,
                                                                int32_t *__restrict__ dst_out,
-                                                               int32_t *__restrict__ milli_out) {
+                                                               int32_t *__restrict__ milli_out, int by_id) {
   constexpr int NV = 2048;  // inv in [0, 2000]
   __shared__ uint32_t hist_all[4][NV];
   __shared__ uint64_t keep_all[4][SEL_MAXK];
@@ -1349,6 +1349,52 @@ __global__ __launch_bounds__(256) void topk_select_long_kernel(const uint64_t *_
       below = __shfl(bl, owner, WAVE);
     }
     const uint32_t want_eq = reach ? (uint32_t)K - below : 0u;  // ties at v* kept, in list order
+    // List order IS ascending neighbour id when the list is the query's two runs (smaller ids in the reverse run,
+    // larger ones in the forward run, each ascending).  A list made of reverse words alone (by_id: edges that
+    // arrived from several scoring ranks) has no such order: the ties to keep are then the want_eq SMALLEST ids
+    // among the elements at v* -- found by a radix select on the id, 11 bits per round (ids are distinct in a list).
+    uint32_t id_cut = 0xFFFFFFFFu;  // ties with id <= id_cut are kept
+    if (by_id && reach && hist[vstar] > want_eq) {  // uniform
+      uint32_t prefix = 0, need = want_eq;          // ids whose top bits equal `prefix` are still undecided
+      for (int shift = 22; shift >= 0; shift -= 11) {
+        __builtin_amdgcn_wave_barrier();
+        for (int v = lane; v < NV; v += WAVE) hist[v] = 0;
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t x = lane; x < len; x += WAVE) {
+          const uint64_t k = sel_key(x, rs, nr, fs, pairs, milli, rev, rdst, id_bits, idm);
+          const uint32_t idv = (uint32_t)k;
+          if ((uint32_t)(k >> 32) == vstar && (shift == 22 || (idv >> (shift + 11)) == prefix))
+            atomicAdd(&hist[(idv >> shift) & (NV - 1)], 1u);
+        }
+        __builtin_amdgcn_wave_barrier();
+        uint32_t ms = 0;
+        for (int v = 0; v < NV / WAVE; ++v) ms += hist[lane * (NV / WAVE) + v];
+        uint32_t ic = ms;
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) {
+          const uint32_t o = __shfl_up(ic, d, WAVE);
+          if (lane >= d) ic += o;
+        }
+        const int owner = __ffsll((long long)__ballot(ic >= need)) - 1;  // (need <= the number of undecided ids)
+        uint32_t run = __shfl(ic - ms, owner, WAVE), dg = 0, bl = 0;
+        if (lane == owner) {
+          for (int v = 0; v < NV / WAVE; ++v) {
+            const uint32_t h = hist[lane * (NV / WAVE) + v];
+            if (run + h >= need) {
+              dg = lane * (NV / WAVE) + v;
+              bl = run;
+              break;
+            }
+            run += h;
+          }
+        }
+        dg = __shfl(dg, owner, WAVE);
+        bl = __shfl(bl, owner, WAVE);
+        prefix = shift == 22 ? dg : (prefix << 11 | dg);
+        need -= bl;                                  // ids below this digit are all kept
+      }
+      id_cut = prefix;                               // the need-th smallest undecided id itself (need == 1 by now)
+    }
     // second sweep, in list order: collect the survivors
     uint32_t nkeep = 0, neq = 0;
     for (uint32_t x0 = 0; x0 < len; x0 += WAVE) {
@@ -1358,7 +1404,8 @@ __global__ __launch_bounds__(256) void topk_select_long_kernel(const uint64_t *_
       const bool lt = x < len && inv < vstar;
       const bool eq = x < len && inv == vstar;
       const uint64_t meq = __ballot(eq);
-      const bool take_eq = eq && neq + (uint32_t)__popcll(meq & lt_mask) < want_eq;
+      const bool take_eq = eq && (id_cut != 0xFFFFFFFFu ? (uint32_t)k <= id_cut
+                                                        : neq + (uint32_t)__popcll(meq & lt_mask) < want_eq);
       const uint64_t mk = __ballot(lt || take_eq);
       if (lt || take_eq) keep[nkeep + (uint32_t)__popcll(mk & lt_mask)] = k;
       nkeep += (uint32_t)__popcll(mk);
@@ -1420,8 +1467,12 @@ QRLSH_EXPORT int qrlsh_topk_select_count(const uint64_t *pairs, int64_t n, const
                    id_bits <= 32,
                "qrlsh_topk_select_count: bad arguments (n=%lld nq=%lld K=%d (<= %d) id_bits=%d)", (long long)n,
                (long long)nq, K, SEL_MAXK, id_bits);
-  QR_CHECK_ARG(rev_dst || id_bits <= 26, "qrlsh_topk_select_count: packed reverse words need id_bits <= 26");
-  QR_CHECK_ARG(total_out && workspace && (n == 0 || (pairs && rev_sorted)), "qrlsh_topk_select_count: null pointer");
+  // packed reverse words: src << (id_bits + 11) | inv << id_bits | neighbour must fit 64 bits
+  QR_CHECK_ARG(rev_dst || id_bits <= 26 || (!pairs && ((uint64_t)(nq - 1) >> (53 - id_bits)) == 0),
+               "qrlsh_topk_select_count: packed reverse words need id_bits <= 26 (or, without a forward list, src < 2^(53 - id_bits))");
+  // pairs == NULL: the lists are made of the n reverse words alone (the sharded driver: every directed edge a rank
+  // receives is such a word, src = its own query)
+  QR_CHECK_ARG(total_out && workspace && (n == 0 || rev_sorted), "qrlsh_topk_select_count: null pointer");
   if (workspace_bytes < qrlsh_topk_select_workspace_bytes(nq)) {
     qrlsh_set_error("qrlsh_topk_select_count: workspace %zu < %zu bytes", workspace_bytes,
                     qrlsh_topk_select_workspace_bytes(nq));
@@ -1439,10 +1490,15 @@ QRLSH_EXPORT int qrlsh_topk_select_count(const uint64_t *pairs, int64_t n, const
     qrlsh_set_error("qrlsh_topk_select_count: hipMemsetAsync failed");
     return QRLSH_EHIP;
   }
-  QR_LAUNCH("topk_bounds", edge_bounds_kernel, dim3((unsigned)ceil_div64(n + 1, 256), 2), blk, 0, st, pairs, rev_sorted, n,
-            nq, id_bits, rev_dst ? 1 : 0, w.fstart, w.rstart);
-  QR_LAUNCH("topk_bounds", edge_bounds_fix_kernel, dim3((unsigned)ceil_div64(nq + 1, 256), 2), blk, 0, st, pairs,
-            rev_sorted, n, nq, id_bits, rev_dst ? 1 : 0, w.fstart, w.rstart);
+  const int lists = pairs ? 2 : 1, y0 = pairs ? 0 : 1;
+  if (!pairs && hipMemsetAsync(w.fstart, 0, (size_t)((char *)w.rstart - (char *)w.fstart), st) != hipSuccess) {
+    qrlsh_set_error("qrlsh_topk_select_count: hipMemsetAsync failed");   // every forward run is empty
+    return QRLSH_EHIP;
+  }
+  QR_LAUNCH("topk_bounds", edge_bounds_kernel, dim3((unsigned)ceil_div64(n + 1, 256), lists), blk, 0, st, pairs, rev_sorted, n,
+            nq, id_bits, rev_dst ? 1 : 0, w.fstart, w.rstart, y0);
+  QR_LAUNCH("topk_bounds", edge_bounds_fix_kernel, dim3((unsigned)ceil_div64(nq + 1, 256), lists), blk, 0, st, pairs,
+            rev_sorted, n, nq, id_bits, rev_dst ? 1 : 0, w.fstart, w.rstart, y0);
   QR_LAUNCH("topk_len", topk_len_kernel, dim3((unsigned)ceil_div64(nq + 1, LEN_QPB)), blk, 0, st, (const uint32_t *)w.fstart,
             (const uint32_t *)w.rstart, nq, K, w.off, w.medlist, w.longlist,
             reinterpret_cast<unsigned long long *>(w.nlong));
@@ -1458,8 +1514,8 @@ QRLSH_EXPORT int qrlsh_topk_select_fill(const uint64_t *pairs, const int32_t *mi
   QR_CHECK_ARG(n >= 0 && n < (1ll << 31) && nq > 0 && K > 0 && K <= SEL_MAXK && id_bits >= 1 && id_bits <= 32,
                "qrlsh_topk_select_fill: bad arguments");
   if (n == 0) return QRLSH_OK;
-  QR_CHECK_ARG(pairs && milli && rev_sorted && workspace && src_out && dst_out && milli_out,
-               "qrlsh_topk_select_fill: null pointer");
+  QR_CHECK_ARG((pairs == nullptr) == (milli == nullptr) && rev_sorted && workspace && src_out && dst_out && milli_out,
+               "qrlsh_topk_select_fill: null pointer (pairs and milli: both or neither)");
   const SelWs w = sel_ws(const_cast<void *>(workspace), nq);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const uint32_t *fsp = w.fstart, *rsp = w.rstart;
@@ -1470,7 +1526,8 @@ QRLSH_EXPORT int qrlsh_topk_select_fill(const uint64_t *pairs, const int32_t *mi
   QR_LAUNCH("topk_select_medium", topk_select_medium_kernel, dim3(SEL_LIST_GRID), dim3(256), 0, st, pairs, milli,
             rev_sorted, rev_dst, fsp, rsp, offp, (const uint32_t *)w.medlist, nl, K, id_bits, src_out, dst_out, milli_out);
   QR_LAUNCH("topk_select_long", topk_select_long_kernel, dim3(SEL_LIST_GRID), dim3(256), 0, st, pairs, milli, rev_sorted,
-            rev_dst, fsp, rsp, offp, (const uint32_t *)w.longlist, nl, K, id_bits, src_out, dst_out, milli_out);
+            rev_dst, fsp, rsp, offp, (const uint32_t *)w.longlist, nl, K, id_bits, src_out, dst_out, milli_out,
+            pairs ? 0 : 1);
   QR_LAUNCH_CHECK("qrlsh_topk_select_fill");
   return QRLSH_OK;
 }

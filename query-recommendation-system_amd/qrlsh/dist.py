@@ -545,7 +545,7 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
     ph.done("7_topk")
     stats["unique_pairs"] = int(pairs.numel())
     stats["kept_edges"] = int(src.numel())
-    stats["topk"] = "sort" if world > 1 else "sort-stable"
+    stats["topk"] = "select (received edges = reverse words, sorted on their src bits)" if world > 1 else "sort-stable"
     stats.update(getattr(be, "stats", {}))
     ph.close()
     return HotPathResult(sig[:n_real], norm2[:n_real], pairs, milli, src, dst, val, K, b, stats)

@@ -682,7 +682,7 @@ def local_bits_for(nql):
     return max(1, int(nql - 1).bit_length()) if nql > 1 else 1
 
 
-def topk_edges_local(edges, edst, K, id_bits, q0, nql):
+def topk_edges_local(edges, edst, K, id_bits, q0, nql, select=True):
     """Per-query top-K from edges that arrived from several scoring ranks (no useful order): re-base the
     src field to this rank's id range, sort the whole (src, 1000 - milli, dst) key, cut.  edst: the dst
     payload of key + payload edges, or None for packed ones."""
@@ -697,6 +697,12 @@ def topk_edges_local(edges, edst, K, id_bits, q0, nql):
         raise NotImplementedError("%d local + %d global id bits do not fit the 64-bit top-K key" % (lb, id_bits))
     loc = torch.empty_like(edges)
     _lib.check(lib.qrlsh_edges_localize(_ptr(edges), _ptr(edst), n, id_bits, int(q0), int(nql), _ptr(loc), _stream()))
+    if select and K <= SELECT_MAX_K and n < (1 << 31):
+        # select form: the re-based keys ARE reverse words (src = a local query); sorted on the src bits alone
+        # (ceil(lb / 8) passes instead of ceil((lb + 11 + id_bits) / 8)), every edge then ranks itself in its query's run
+        src, dst, val = topk_select(None, None, loc, K, id_bits, int(nql))
+        src += int(q0)
+        return src, dst, val
     se, _ = sort_u64(loc, None, 0, lb + 11 + id_bits)
     ws = _ws(lib.qrlsh_compact_workspace_bytes(n), dev)
     total = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -736,20 +742,23 @@ SELECT_MAX_K = 256   # SEL_MAXK in csrc/pairs.hip
 def topk_select(pairs, milli, rev, K, id_bits, nq):
     """Per-query top-K (recommender.py:206-210) from the sorted scored pairs and their reverse words
     (score_pairs_rev): the reverse words are sorted on j's bits only, then every directed edge ranks itself
-    inside its query's two runs.  -> (src, dst, milli) int32, the same COO topk_edges returns."""
+    inside its query's two runs.  -> (src, dst, milli) int32, the same COO topk_edges returns.
+    pairs = milli = None: the lists are made of the reverse words alone (packed words src << (id_bits + 11) |
+    inv << id_bits | neighbour with src < nq: topk_edges_local)."""
     lib = _lib.load()
     rdst = None
     if isinstance(rev, tuple):
         rev, rdst = rev
-    dev = pairs.device
-    n = pairs.numel()
+    dev = rev.device
+    n = rev.numel()
     if n == 0:
         z = torch.empty((0,), dtype=torch.int32, device=dev)
         return z, z.clone(), z.clone()
     if K > SELECT_MAX_K:
         raise ValueError("topk_select handles K <= %d; use topk_edges (the sort form) beyond" % SELECT_MAX_K)
     if rdst is None:
-        rs, rd = sort_u64(rev, None, id_bits + 11, 2 * id_bits + 11)
+        src_bits = id_bits if pairs is not None else local_bits_for(nq)
+        rs, rd = sort_u64(rev, None, id_bits + 11, id_bits + 11 + src_bits)
     else:
         rs, rd = sort_u64(rev, rdst, 11, 11 + id_bits)
     ws = _ws(lib.qrlsh_topk_select_workspace_bytes(nq), dev)

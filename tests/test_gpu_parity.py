@@ -993,6 +993,46 @@ def test_multi_gpu_glue_kernels_match_numpy():
 
 
 # ---------------------------------------------------------------------------- fast bucket path
+@pytest.mark.parametrize("wide", [False, True])
+def test_local_topk_select_form_equals_sort_form(wide):
+    """the top-K of the sharded driver's step 7: the edges a rank receives (any order, from several scoring ranks),
+    re-based to its id range, cut by the select form (sorted on the src bits only, every edge ranks itself in its
+    query's run) and by the full (src, value, dst) sort -- identical COO, short / medium / long lists and ties included"""
+    rng = np.random.default_rng(31 + wide)
+    ib, q0, nql, K = (27 if wide else 22), 3_000_000, 50_000, 40
+    deg = rng.integers(0, 30, size=nql)
+    deg[rng.choice(nql, 40, replace=False)] = rng.integers(100, 3000, size=40)      # long lists
+    src = np.repeat(np.arange(nql), deg) + q0
+    n = len(src)
+    dst = rng.integers(0, 1 << ib, size=n)
+    inv = rng.integers(0, 40, size=n)                                               # few values: many ties at the cut
+    perm = rng.permutation(n)
+    src, dst, inv = src[perm], dst[perm], inv[perm]
+    if wide:
+        keys = (src.astype(np.uint64) << np.uint64(11)) | inv.astype(np.uint64)
+        e, d = dev(keys.view(np.int64)), dev(dst.astype(np.int32))
+    else:
+        keys = (src.astype(np.uint64) << np.uint64(ib + 11)) | (inv.astype(np.uint64) << np.uint64(ib)) | dst.astype(np.uint64)
+        e, d = dev(keys.view(np.int64)), None
+    # the data must be able to tell "ties at the cut in arrival order" from "ties at the cut by ascending id" (what the
+    # sort form -- and the reference's documented tie-break -- keeps): count the long lists where the two differ
+    differ = 0
+    for q in np.flatnonzero(deg > 64)[:20]:
+        sel = np.flatnonzero(src == q + q0)                      # arrival order
+        iv, ids = inv[sel], dst[sel]
+        cut = np.sort(iv)[K - 1]
+        ties, want = np.flatnonzero(iv == cut), K - int((iv < cut).sum())
+        differ += set(ids[ties[:want]]) != set(np.sort(ids[ties])[:want])
+    assert differ > 0
+    a = ops.topk_edges_local(e.clone(), d, K, ib, q0, nql, select=True)
+    b = ops.topk_edges_local(e.clone(), d, K, ib, q0, nql, select=False)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    s_, _, v_ = (t.cpu().numpy() for t in a)
+    assert s_.min() >= q0 and s_.max() < q0 + nql and np.bincount(s_ - q0).max() == K and len(s_) == int(np.minimum(deg, K).sum())
+    assert (v_ == 1000 - np.sort(inv)[0]).any()
+
+
 def test_gather_sets_out_of_replicated_shards():
     """qrlsh_gather_sets_* ("sets" mode of the sharded driver): the answer sets of chosen global query ids out of the
     per-shard arrays as the all-gather leaves them -- 16- / 32-bit row ids, 32- / 64-bit offsets, padded shards --
