@@ -1,0 +1,21 @@
+import sys, time, torch
+sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/query-recommendation-system_amd")
+import qrlsh
+from qrlsh import ops, pipeline
+nq, D = 10_000_000, 32768
+off, rows = qrlsh.synth_csr(nq, D, seed=0, device="cuda")
+table = ops.perm_table(ops.legacy_permutations(128, D, seed=42), "cuda")
+ho, hr = off.cpu(), rows.cpu()
+po, pr = ho.pin_memory(), hr.pin_memory()
+def t(fn, n=5):
+    fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
+print("H2D pageable  %.1f ms" % t(lambda: (ho.to("cuda"), hr.to("cuda"))))
+print("H2D pinned    %.1f ms" % t(lambda: (po.to("cuda", non_blocking=True), pr.to("cuda", non_blocking=True))))
+res = pipeline.query_similarities(off, rows, table, 32, 40, validate=False)
+print("D2H top-K (%.0f MB) pageable %.1f ms" % (res.src.numel() * 12 / 1e6, t(lambda: (res.src.cpu(), res.dst.cpu(), res.val.cpu()))))
+def full():
+    o, r = po.to("cuda", non_blocking=True), pr.to("cuda", non_blocking=True)
+    return pipeline.query_similarities(o, r, table, 32, 40, validate=True)
+print("pinned H2D + check_csr + step %.1f ms" % t(full))
