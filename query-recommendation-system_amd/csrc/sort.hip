@@ -772,6 +772,8 @@ QRLSH_EXPORT int qrlsh_owner_bounds(const uint64_t *words, int64_t n, int32_t bi
 constexpr int FIN_THREADS = QR_FIN_THREADS;
 constexpr int FIN_CAP = QR_FIN_CAP;   // records per part that fit the LDS image
 constexpr int FIN_IPT = FIN_CAP / FIN_THREADS;
+constexpr int FIN_SMALL_THREADS = 512, FIN_SMALL_CAP = 4096;  // the small-part form of the one-pass finish
+constexpr int FIN_SMALL_MEAN = 2800;                          // mean records per part up to which it is used
 
 // starts[band][f] = first position of band `band` whose T-bit part number is >= f (f = 0 .. 2^T)
 __global__ __launch_bounds__(256) void bucket_bounds_kernel(const uint64_t *__restrict__ keys,
@@ -804,13 +806,13 @@ __global__ __launch_bounds__(256) void bucket_bounds_kernel(const uint64_t *__re
 // LDS: table 48 KB + counters 24 KB = 72 KB -> two 1024-thread workgroups per CU (which also
 // needs <= 64 VGPRs: __launch_bounds__(1024, 8)).  Arrival order varies from run to run, so the
 // pairs of a part come out in varying order -- as a set they are exact, and the next step sorts.
-__device__ static inline uint32_t fin_home(uint64_t key) {
+template <int CAP = FIN_CAP> __device__ static inline uint32_t fin_home(uint64_t key) {
   uint32_t h = (uint32_t)key * 0x9E3779B1u;
   h ^= h >> 15;
   h += (uint32_t)(key >> 32) * 0x85EBCA77u;
   h ^= h >> 13;
   h *= 0xC2B2AE3Du;
-  return __umulhi(h, (uint32_t)FIN_CAP);
+  return __umulhi(h, (uint32_t)CAP);
 }
 
 // The pairs of one record with the `c` ids at run[0 .. c) go to dst[pos .. pos + c).  A short run is written by the
@@ -849,8 +851,12 @@ __device__ static inline void emit_run(uint64_t *__restrict__ dst, uint32_t pos,
 // one atomicAdd on a global cursor (blk[0]) and writes only if the range fits `capacity`; the cursor
 // ends up holding the exact total either way, so a caller whose guess was too small retries once.
 enum { FIN_COUNT = 0, FIN_FILL = 1, FIN_EMIT = 2 };
-template <int MODE>
-__global__ __launch_bounds__(FIN_THREADS, 8) void bucket_finish_kernel(const uint64_t *__restrict__ keys,
+// THREADS / CAP: the workgroup and its LDS image.  1024 / 6144 (72 KB: two workgroups per CU) is the general form; when
+// the parts are small (mean <= FIN_SMALL_MEAN records: 10 M queries and beyond), 512 / 4096 (48 KB) puts THREE
+// independent chains of phases on a CU instead of two (2.51 -> 2.12 ms at 10 M), and a part between 4096 and 6144
+// records joins the ones the big kernel works in blocks.
+template <int MODE, int THREADS = FIN_THREADS, int CAP = FIN_CAP>
+__global__ __launch_bounds__(THREADS, THREADS >= 1024 ? 8 : 6) void bucket_finish_kernel(const uint64_t *__restrict__ keys,
                                                                        const uint32_t *__restrict__ ids, int64_t nq,
                                                                        const uint32_t *__restrict__ starts,
                                                                        int nparts, uint64_t ek,
@@ -864,10 +870,12 @@ __global__ __launch_bounds__(FIN_THREADS, 8) void bucket_finish_kernel(const uin
                                                                        unsigned long long *__restrict__ nbig = nullptr,
                                                                        uint32_t big_max = 0, uint32_t big_base = 0) {
   constexpr bool FILL = MODE != FIN_COUNT;
+  constexpr int IPT = CAP / THREADS;
+  static_assert(CAP % THREADS == 0 && CAP <= 65535, "image = whole records per thread, slots fit 16 bits");
   __shared__ unsigned long long gbase;
-  __shared__ __attribute__((aligned(16))) unsigned long long tab[FIN_CAP];
-  __shared__ uint32_t cnt[FIN_CAP];
-  __shared__ uint32_t wsum[FIN_THREADS / WAVE];
+  __shared__ __attribute__((aligned(16))) unsigned long long tab[CAP];
+  __shared__ uint32_t cnt[CAP];
+  __shared__ uint32_t wsum[THREADS / WAVE];
   const int part = blockIdx.x, band = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid >> 6;
   const size_t bslot = (size_t)band * nparts + part;
@@ -876,7 +884,7 @@ __global__ __launch_bounds__(FIN_THREADS, 8) void bucket_finish_kernel(const uin
   const uint32_t start = counts ? 0u : starts[(size_t)band * (nparts + 1) + part];
   const uint32_t m = counts ? counts[bslot] : starts[(size_t)band * (nparts + 1) + part + 1] - start;
   const size_t first = counts ? bslot * cap : (size_t)band * nq + start;
-  if (m > (uint32_t)FIN_CAP || (counts && m > cap)) {  // uniform over the workgroup
+  if (m > (uint32_t)CAP || (counts && m > cap)) {  // uniform over the workgroup
     if (tid == 0) {
       // a part that holds more records than the LDS image (a popular key with thousands of copies, mostly) but
       // fits its region: left to bucket_finish_big_kernel, which works it in blocks -- one-pass form only
@@ -900,46 +908,46 @@ __global__ __launch_bounds__(FIN_THREADS, 8) void bucket_finish_kernel(const uin
   }
   const uint64_t *k = keys + first;
   const uint32_t *id = ids + first;
-  uint64_t kreg[FIN_IPT];
-  uint32_t ireg[FIN_IPT];
+  uint64_t kreg[IPT];
+  uint32_t ireg[IPT];
 #pragma unroll
-  for (int j = 0; j < FIN_IPT; ++j) {
-    const uint32_t i = tid + j * FIN_THREADS;
+  for (int j = 0; j < IPT; ++j) {
+    const uint32_t i = tid + j * THREADS;
     kreg[j] = i < m ? k[i] : ek;
     if (FILL) ireg[j] = i < m ? id[i] : 0u;  // coalesced, in flight together with the keys
   }
 #pragma unroll
-  for (int j = 0; j < FIN_IPT; ++j) {
-    const uint32_t i = tid + j * FIN_THREADS;
+  for (int j = 0; j < IPT; ++j) {
+    const uint32_t i = tid + j * THREADS;
     tab[i] = ek;
     cnt[i] = 0;
   }
   __syncthreads();
-  uint32_t so[FIN_IPT];  // arrival number << 16 | slot (both < FIN_CAP <= 65535); 0xFFFFFFFF = empty band
+  uint32_t so[IPT];  // arrival number << 16 | slot (both < FIN_CAP <= 65535); 0xFFFFFFFF = empty band
   uint32_t mine = 0;
-  // first probes of all FIN_IPT records go out together (independent LDS atomics in flight), the
+  // first probes of all IPT records go out together (independent LDS atomics in flight), the
   // occasional second and later probes follow per record, then all the counter increments together
-  uint32_t slot[FIN_IPT];
-  unsigned long long seen[FIN_IPT];
+  uint32_t slot[IPT];
+  unsigned long long seen[IPT];
 #pragma unroll
-  for (int j = 0; j < FIN_IPT; ++j) {
-    slot[j] = fin_home(kreg[j]);
+  for (int j = 0; j < IPT; ++j) {
+    slot[j] = fin_home<CAP>(kreg[j]);
     seen[j] = kreg[j] != ek
                   ? atomicCAS(&tab[slot[j]], (unsigned long long)ek, (unsigned long long)kreg[j])
                   : (unsigned long long)ek;
   }
 #pragma unroll
-  for (int j = 0; j < FIN_IPT; ++j) {
+  for (int j = 0; j < IPT; ++j) {
     if (kreg[j] != ek) {
       unsigned long long old = seen[j];
       while (old != ek && old != kreg[j]) {  // FIN_CAP slots for at most FIN_CAP records: a free one always turns up
-        slot[j] = slot[j] + 1 == (uint32_t)FIN_CAP ? 0u : slot[j] + 1;
+        slot[j] = slot[j] + 1 == (uint32_t)CAP ? 0u : slot[j] + 1;
         old = atomicCAS(&tab[slot[j]], (unsigned long long)ek, (unsigned long long)kreg[j]);
       }
     }
   }
 #pragma unroll
-  for (int j = 0; j < FIN_IPT; ++j) {
+  for (int j = 0; j < IPT; ++j) {
     so[j] = 0xFFFFFFFFu;
     if (kreg[j] != ek) {
       const uint32_t o = atomicAdd(&cnt[slot[j]], 1u);
@@ -958,7 +966,7 @@ __global__ __launch_bounds__(FIN_THREADS, 8) void bucket_finish_kernel(const uin
   __syncthreads();  // also: every insert is over
   uint32_t base = 0, tot = 0;
 #pragma unroll
-  for (int i = 0; i < FIN_THREADS / WAVE; ++i) {
+  for (int i = 0; i < THREADS / WAVE; ++i) {
     const uint32_t x = wsum[i];
     if (i < w) base += x;
     tot += x;
@@ -975,11 +983,11 @@ __global__ __launch_bounds__(FIN_THREADS, 8) void bucket_finish_kernel(const uin
   }
   const uint32_t pos0 = base + inc - mine;
   {
-    // run starts: exclusive scan of the slot counters, blocked layout (FIN_IPT consecutive slots per thread)
-    const uint32_t b0 = tid * FIN_IPT;
-    uint32_t v[FIN_IPT], sum = 0;
+    // run starts: exclusive scan of the slot counters, blocked layout (IPT consecutive slots per thread)
+    const uint32_t b0 = tid * IPT;
+    uint32_t v[IPT], sum = 0;
 #pragma unroll
-    for (int q = 0; q < FIN_IPT; ++q) {
+    for (int q = 0; q < IPT; ++q) {
       v[q] = cnt[b0 + q];
       sum += v[q];
     }
@@ -994,10 +1002,10 @@ __global__ __launch_bounds__(FIN_THREADS, 8) void bucket_finish_kernel(const uin
     __syncthreads();
     uint32_t run = sinc - sum;
 #pragma unroll
-    for (int i = 0; i < FIN_THREADS / WAVE; ++i)
+    for (int i = 0; i < THREADS / WAVE; ++i)
       if (i < w) run += wsum[i];
 #pragma unroll
-    for (int q = 0; q < FIN_IPT; ++q) {
+    for (int q = 0; q < IPT; ++q) {
       cnt[b0 + q] = run;
       run += v[q];
     }
@@ -1005,7 +1013,7 @@ __global__ __launch_bounds__(FIN_THREADS, 8) void bucket_finish_kernel(const uin
   __syncthreads();
   uint32_t *grp = reinterpret_cast<uint32_t *>(tab);  // the table is dead: ids, bucket by bucket
 #pragma unroll
-  for (int j = 0; j < FIN_IPT; ++j)
+  for (int j = 0; j < IPT; ++j)
     if (so[j] != 0xFFFFFFFFu) grp[cnt[so[j] & 0xFFFFu] + (so[j] >> 16)] = ireg[j];
   __syncthreads();
   {
@@ -1014,7 +1022,7 @@ __global__ __launch_bounds__(FIN_THREADS, 8) void bucket_finish_kernel(const uin
     uint64_t *dst = out + obase;
     uint32_t pos = pos0;
 #pragma unroll
-    for (int j = 0; j < FIN_IPT; ++j) {
+    for (int j = 0; j < IPT; ++j) {
       const bool rec = so[j] != 0xFFFFFFFFu;
       const uint32_t o = rec ? so[j] >> 16 : 0u;
       emit_run(dst, pos, ireg[j], grp, rec ? cnt[so[j] & 0xFFFFu] : 0u, o);
@@ -1036,6 +1044,7 @@ constexpr int FIN_BIG_GRID = 256;
 #endif
 constexpr int FIN_BIG_FACTOR = QR_FIN_BIG_FACTOR;  // a part's region holds this many LDS images
 constexpr uint32_t FIN_BIG_LIST = 65536;  // listed parts per call; beyond: overflow flag (general path)
+constexpr int FIN_BIG_SLICES = 8;         // workgroups that share a block pair's pairs (a power of two)
 __global__ __launch_bounds__(FIN_THREADS) void bucket_finish_big_kernel(
     const uint64_t *__restrict__ keys, const uint32_t *__restrict__ ids, const uint32_t *__restrict__ counts, uint32_t cap,
     uint64_t ek, const uint64_t *__restrict__ biglist, const unsigned long long *__restrict__ nbig, uint32_t big_max,
@@ -1044,6 +1053,7 @@ __global__ __launch_bounds__(FIN_THREADS) void bucket_finish_big_kernel(
   __shared__ __attribute__((aligned(16))) unsigned long long tab[FIN_CAP];
   __shared__ uint32_t cnt[FIN_CAP + 1];
   __shared__ uint32_t grp[FIN_CAP];
+  __shared__ uint32_t srt[FIN_CAP];   // the runs in id order (own pairs of a block)
   __shared__ uint32_t wsum[FIN_THREADS / WAVE];
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid >> 6;
   unsigned long long nb = *nbig;
@@ -1069,12 +1079,19 @@ __global__ __launch_bounds__(FIN_THREADS) void bucket_finish_big_kernel(
     total = tot;
     return base + inc - v;
   };
-  // work items: (listed part, block bi, block bj <= bi) -- the table of bi is built, then bi's own pairs (bj = bi)
-  // or the pairs of bj's records with it are written; a part's items run on different workgroups
+  // work items: (listed part, block bi, block bj <= bi, slice sl) -- the table of bi is built, then an eighth of bi's
+  // own pairs (bj = bi) or of the pairs of bj's records with it is written; a part's items run on different
+  // workgroups, so that a key with thousands of copies (1.4 M pairs for 1 700 copies: 0.35 ms when one workgroup
+  // writes them all) is the work of eight.  Every workgroup builds the table itself and the arrival numbers differ
+  // from build to build, so a slice is defined on something the builds share: bi's own pairs go by the RANK of a
+  // record's query id among its bucket-mates (the runs are sorted by id; a record pairs with the mates of smaller
+  // id, and belongs to slice rank mod 8), bj's records by their position in bj (mod 8).
   constexpr int COMBOS = FIN_BIG_FACTOR * (FIN_BIG_FACTOR + 1) / 2;
-  for (unsigned long long item = blockIdx.x; item < nb * COMBOS; item += gridDim.x) {
-    const unsigned long long e = item / COMBOS;
-    int combo = (int)(item - e * COMBOS);
+  static_assert(FIN_THREADS % FIN_BIG_SLICES == 0, "a thread's records share their position mod the slice count");
+  for (unsigned long long item = blockIdx.x; item < nb * COMBOS * FIN_BIG_SLICES; item += gridDim.x) {
+    const uint32_t sl = (uint32_t)(item % FIN_BIG_SLICES);
+    const unsigned long long e = item / ((unsigned long long)COMBOS * FIN_BIG_SLICES);
+    int combo = (int)((item / FIN_BIG_SLICES) % COMBOS);
     uint32_t bi = 0;
     while (combo > (int)bi) {  // combos in the order (0,0) (1,0) (1,1) (2,0) (2,1) (2,2)
       combo -= (int)bi + 1;
@@ -1101,7 +1118,6 @@ __global__ __launch_bounds__(FIN_THREADS) void bucket_finish_big_kernel(
         cnt[i] = 0;
       }
       __syncthreads();
-      uint32_t mine = 0;
 #pragma unroll
       for (int j = 0; j < FIN_IPT; ++j) {
         so[j] = 0xFFFFFFFFu;
@@ -1114,11 +1130,9 @@ __global__ __launch_bounds__(FIN_THREADS) void bucket_finish_big_kernel(
           }
           const uint32_t o = atomicAdd(&cnt[slot], 1u);
           so[j] = o << 16 | slot;
-          mine += o;
         }
       }
-      uint32_t tot;
-      const uint32_t pos0 = scan(mine, tot);  // (its barriers also end the inserts)
+      __syncthreads();  // every insert is over
       {
         // run starts: exclusive scan of the slot counters, blocked layout; cnt[FIN_CAP] = the block's record count
         const uint32_t b0 = tid * FIN_IPT;
@@ -1141,19 +1155,47 @@ __global__ __launch_bounds__(FIN_THREADS) void bucket_finish_big_kernel(
 #pragma unroll
       for (int j = 0; j < FIN_IPT; ++j)
         if (so[j] != 0xFFFFFFFFu) grp[cnt[so[j] & 0xFFFFu] + (so[j] >> 16)] = ireg[j];
-      if (tid == 0 && tot && bj_only == bi)
-        gbase = __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(blk), (unsigned long long)tot, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-      __syncthreads();
-      if (bj_only == bi && tot && gbase + tot <= capacity) {  // uniform; counted either way
-        uint64_t *dst = out + gbase;
-        uint32_t pos = pos0;
+      __syncthreads();  // the runs are laid out (in this build's arrival order)
+      if (bj_only == bi) {
+        // this block's own pairs.  Rank of every record's id among its run (ids are distinct inside a bucket), the runs
+        // re-laid in id order, then a record of rank r pairs with the r mates in front of it -- if r mod 8 is this slice
+        uint32_t rk[FIN_IPT];
 #pragma unroll
         for (int j = 0; j < FIN_IPT; ++j) {
-          const bool rec = so[j] != 0xFFFFFFFFu;
-          const uint32_t o = rec ? so[j] >> 16 : 0u;
-          emit_run(dst, pos, ireg[j], grp, rec ? cnt[so[j] & 0xFFFFu] : 0u, o);
-          pos += o;
+          rk[j] = 0;
+          if (so[j] != 0xFFFFFFFFu) {
+            // (a lane per record: the copies of a popular key fill whole waves, which then walk the run in step --
+            // counting a long run with the whole wave, one record after the other, was 2.5x slower)
+            const uint32_t sl0 = so[j] & 0xFFFFu, s0 = cnt[sl0], c = cnt[sl0 + 1] - s0, me = ireg[j];
+            uint32_t r = 0;
+            for (uint32_t u = 0; u < c; ++u) r += grp[s0 + u] < me;
+            rk[j] = r;
+          }
+        }
+        __syncthreads();  // every rank is known: the runs may move
+#pragma unroll
+        for (int j = 0; j < FIN_IPT; ++j)
+          if (so[j] != 0xFFFFFFFFu) srt[cnt[so[j] & 0xFFFFu] + rk[j]] = ireg[j];
+        uint32_t mine = 0;
+#pragma unroll
+        for (int j = 0; j < FIN_IPT; ++j) {
+          if (so[j] == 0xFFFFFFFFu || (rk[j] & (FIN_BIG_SLICES - 1)) != sl) rk[j] = 0;  // not this slice's: no pairs
+          mine += rk[j];
+        }
+        uint32_t tot;
+        const uint32_t pos0 = scan(mine, tot);  // (its barriers also end the re-layout)
+        if (tid == 0 && tot)
+          gbase = __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(blk), (unsigned long long)tot,
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (tot && gbase + tot <= capacity) {  // uniform; counted either way
+          uint64_t *dst = out + gbase;
+          uint32_t pos = pos0;
+#pragma unroll
+          for (int j = 0; j < FIN_IPT; ++j) {
+            emit_run(dst, pos, ireg[j], srt, so[j] != 0xFFFFFFFFu ? cnt[so[j] & 0xFFFFu] : 0u, rk[j]);
+            pos += rk[j];
+          }
         }
       }
       // the records of an earlier block against this block's table
@@ -1168,7 +1210,8 @@ __global__ __launch_bounds__(FIN_THREADS) void bucket_finish_big_kernel(
           const uint64_t x = k[lo2 + i];
           ireg[j] = id[lo2 + i];
           uint32_t slot = fin_home(x), found = 0xFFFFFFFFu;
-          for (int step = 0; step < FIN_CAP; ++step) {  // (bounded: a full table has no free slot to stop at)
+          const bool my_slice = (uint32_t)(tid & (FIN_BIG_SLICES - 1)) == sl;
+          for (int step = 0; my_slice && step < FIN_CAP; ++step) {  // (bounded: a full table has no free slot to stop at)
             const unsigned long long tv = tab[slot];
             if (tv == x) {
               found = slot;
@@ -1177,6 +1220,7 @@ __global__ __launch_bounds__(FIN_THREADS) void bucket_finish_big_kernel(
             if (tv == ek) break;
             slot = slot + 1 == (uint32_t)FIN_CAP ? 0u : slot + 1;
           }
+          if ((uint32_t)(tid & (FIN_BIG_SLICES - 1)) != sl) found = 0xFFFFFFFFu;  // another slice's record of bj
           hit[j] = found;
           if (found != 0xFFFFFFFFu) mine2 += cnt[found + 1] - cnt[found];
         }
@@ -1429,15 +1473,18 @@ QRLSH_EXPORT int qrlsh_bucket_pairs_emit_chunked(const uint64_t *keys, int64_t k
       return QRLSH_EHIP;
     }
     uint32_t *ovf = reinterpret_cast<uint32_t *>(total_overflow_out + 1);
-    // list of the parts that outgrow the LDS image (bucket_finish_big_kernel): in the count / fill form's block area
-    uint64_t *biglist = w.blk;
-    unsigned long long *nbig = reinterpret_cast<unsigned long long *>(w.tail + 2);
-    const uint64_t slots = (uint64_t)b << T;
-    const uint32_t big_max = (uint32_t)(slots < FIN_BIG_LIST ? slots : FIN_BIG_LIST);
-    if (hipMemsetAsync(nbig, 0, sizeof(unsigned long long), st) != hipSuccess) {
+    // lists of the parts that outgrow the LDS image (bucket_finish_big_kernel), one per band group, in the count /
+    // fill form's block area: [16 counters][group 0's list][group 1's list] ...
+    constexpr int MAX_GROUPS = 16;
+    unsigned long long *nbig0 = reinterpret_cast<unsigned long long *>(w.blk);
+    uint64_t *biglist0 = w.blk + MAX_GROUPS;
+    const uint64_t slots = (uint64_t)b << T;  // >= 256 words in the block area
+    if (hipMemsetAsync(nbig0, 0, MAX_GROUPS * sizeof(unsigned long long), st) != hipSuccess) {
       qrlsh_set_error("qrlsh_bucket_pairs_emit: hipMemsetAsync failed");
       return QRLSH_EHIP;
     }
+    // small parts (and regions that can hold what the small image cannot): the 512-thread / 4096-slot finish
+    const bool small_parts = (nq >> T) <= FIN_SMALL_MEAN && cap2 > (uint32_t)FIN_SMALL_CAP;
     const int ntiles = (int)ceil_div64(nq, PS_TILE);
     const int64_t band_words = key_band_stride ? key_band_stride : nq;  // words between two bands of the key matrix
     static int groups_env = -1;
@@ -1448,13 +1495,19 @@ QRLSH_EXPORT int qrlsh_bucket_pairs_emit_chunked(const uint64_t *keys, int64_t k
     }
     // small inputs: one group (the second stream's fork / join and the extra launches cost more than the overlap
     // gives: 1.71 against 1.67 ms per step at 1 M queries x 32 bands)
-    const int GROUPS = (int64_t)b * nq >= (64ll << 20) ? groups_env : 1;
+    int GROUPS = (int64_t)b * nq >= (64ll << 20) ? groups_env : 1;
+    if (GROUPS > MAX_GROUPS) GROUPS = MAX_GROUPS;
     const int per = (b + GROUPS - 1) / GROUPS;
+    const int ngroups = (b + per - 1) / per;
+    const uint64_t list_room = (slots - MAX_GROUPS) / (uint64_t)ngroups;
+    const uint32_t big_max = (uint32_t)(list_room < FIN_BIG_LIST ? list_room : FIN_BIG_LIST);
     hipStream_t aux = nullptr;
     int gi = 0;
     for (int g0 = 0; g0 < b; g0 += per, ++gi) {
       const int nb = (b - g0 < per) ? b - g0 : per;
       hipStream_t s = (aux && (gi & 1)) ? aux : st;
+      uint64_t *biglist = biglist0 + (size_t)gi * big_max;
+      unsigned long long *nbig = nbig0 + gi;
       uint64_t *k1 = two ? tmp_keys : part_keys;
       uint32_t *v1 = two ? tmp_ids : part_ids;
       QR_PART_SCATTER(false, dim3(ntiles, nb), dim3(SORT_THREADS), 0, s, keys + (size_t)g0 * band_words,
@@ -1472,16 +1525,24 @@ QRLSH_EXPORT int qrlsh_bucket_pairs_emit_chunked(const uint64_t *keys, int64_t k
       // second group's partition then starts beside the first group's finish, and the two streams stay half a
       // group out of step
       if (gi == 0 && b > per) aux = qr_aux_fork(st);
-      QR_LAUNCH("bucket_emit", (bucket_finish_kernel<FIN_EMIT>), dim3(nparts, nb), dim3(FIN_THREADS), 0, s,
-                (const uint64_t *)part_keys + ((size_t)g0 << T) * cap2, (const uint32_t *)part_ids + ((size_t)g0 << T) * cap2,
-                nq, (const uint32_t *)nullptr, nparts, ekx, total_overflow_out, ovf, pairs_out, capacity,
-                (const uint32_t *)cur2 + ((size_t)g0 << T), cap2, biglist, nbig, big_max, (uint32_t)((size_t)g0 << T));
+      if (small_parts)
+        QR_LAUNCH("bucket_emit", (bucket_finish_kernel<FIN_EMIT, FIN_SMALL_THREADS, FIN_SMALL_CAP>), dim3(nparts, nb),
+                  dim3(FIN_SMALL_THREADS), 0, s, (const uint64_t *)part_keys + ((size_t)g0 << T) * cap2,
+                  (const uint32_t *)part_ids + ((size_t)g0 << T) * cap2, nq, (const uint32_t *)nullptr, nparts, ekx,
+                  total_overflow_out, ovf, pairs_out, capacity, (const uint32_t *)cur2 + ((size_t)g0 << T), cap2, biglist, nbig,
+                  big_max, (uint32_t)((size_t)g0 << T));
+      else
+        QR_LAUNCH("bucket_emit", (bucket_finish_kernel<FIN_EMIT>), dim3(nparts, nb), dim3(FIN_THREADS), 0, s,
+                  (const uint64_t *)part_keys + ((size_t)g0 << T) * cap2, (const uint32_t *)part_ids + ((size_t)g0 << T) * cap2,
+                  nq, (const uint32_t *)nullptr, nparts, ekx, total_overflow_out, ovf, pairs_out, capacity,
+                  (const uint32_t *)cur2 + ((size_t)g0 << T), cap2, biglist, nbig, big_max, (uint32_t)((size_t)g0 << T));
+      // the parts of this group the finish listed as larger than its LDS image (usually none: the kernel then finds
+      // an empty list), on the group's own stream: they are worked beside the next group
+      QR_LAUNCH("bucket_emit_big", bucket_finish_big_kernel, dim3(FIN_BIG_GRID), dim3(FIN_THREADS), 0, s,
+                (const uint64_t *)part_keys, (const uint32_t *)part_ids, (const uint32_t *)cur2, cap2, ekx,
+                (const uint64_t *)biglist, (const unsigned long long *)nbig, big_max, total_overflow_out, pairs_out, capacity);
     }
     if (aux) qr_aux_join(st);
-    // the parts the finish listed as larger than its LDS image (usually none: the kernel then finds an empty list)
-    QR_LAUNCH("bucket_emit_big", bucket_finish_big_kernel, dim3(FIN_BIG_GRID), dim3(FIN_THREADS), 0, st,
-              (const uint64_t *)part_keys, (const uint32_t *)part_ids, (const uint32_t *)cur2, cap2, ekx,
-              (const uint64_t *)biglist, (const unsigned long long *)nbig, big_max, total_overflow_out, pairs_out, capacity);
     QR_LAUNCH_CHECK("qrlsh_bucket_pairs_emit");
     return QRLSH_OK;
   }

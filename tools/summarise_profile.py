@@ -32,8 +32,8 @@ LABELS = [
     (r"^minhash_", "minhash"), (r"^band_keys_kernel", "band_keys"), (r"^row_norms_kernel", "row_norms"),
     (r"^sort_hist_kernel", "sort_hist"), (r"^sort_rowscan_kernel", "sort_rowscan"),
     (r"^sort_scatter_kernel<\d+, false", "sort_scatter_k"), (r"^sort_scatter_kernel<\d+, true", "sort_scatter_kv"),
-    (r"^bucket_finish_kernel<0>", "bucket_count"), (r"^bucket_finish_kernel<1>", "bucket_fill"),
-    (r"^bucket_finish_kernel<2>", "bucket_emit"), (r"^bucket_bounds_kernel", "bucket_bounds"),
+    (r"^bucket_finish_kernel<0[,>]", "bucket_count"), (r"^bucket_finish_kernel<1[,>]", "bucket_fill"),
+    (r"^bucket_finish_kernel<2[,>]", "bucket_emit"), (r"^bucket_bounds_kernel", "bucket_bounds"),
     (r"^bucket_finish_big_kernel", "bucket_emit_big"),
     (r"^pairs_count_kernel", "pairs_count"), (r"^pairs_fill_kernel", "pairs_fill"),
     (r"^row_unique_kernel", "row_unique"), (r"^row_unique_gather_kernel", "row_unique_gather"),
