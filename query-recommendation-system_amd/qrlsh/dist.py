@@ -174,12 +174,13 @@ def _owned_bands(recv, world, nb, nql):
 _BG_GROUPS = {}
 
 
-def background_group(group=None):
+def background_group(group=None, force=False):
     """A second communicator over the same ranks for the long signature all-gather, so that it
     runs beside the short exchanges instead of ahead of them (collectives of ONE communicator
-    execute in issue order).  Created collectively on first use, then cached."""
+    execute in issue order).  Created collectively on first use, then cached.
+    force: make the second communicator even for one rank (the RCCL rehearsal of force_collectives)."""
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not force:
         return group
     key = id(group) if group is not None else 0
     if key not in _BG_GROUPS:
@@ -288,37 +289,56 @@ class _Phases:
             self.sink["ms:" + name] = self.sink.get("ms:" + name, 0.0) + a.elapsed_time(e)
 
 
-def _gather_answer_sets(offsets, rows, table, nql, world, group, ph):
+class _Pending:
+    """handle of an asynchronous collective that keeps its SEND buffer referenced until wait() returns: the buffers
+    are temporaries of the issuing function, and nothing but ProcessGroupNCCL's own bookkeeping would otherwise keep
+    the allocator from handing their memory to the next kernel while the collective still reads it"""
+
+    def __init__(self, handle, *buffers):
+        self.handle, self.buffers = handle, buffers
+
+    def wait(self):
+        if self.handle is not None:
+            self.handle.wait()
+        self.handle, self.buffers = None, ()
+
+
+def _gather_answer_sets(offsets, rows, table, nql, world, group, ph, force=False):
     """asynchronous all-gather (second communicator) of every shard's answer sets: row ids padded to the largest
     shard + the nql + 1 offsets.  On the wire the row ids are 16-bit words when the table has at most 65536 rows and
     the offsets 32-bit ones (a shard holds fewer than 2^31 row ids): 34 instead of 72 bytes per query of mean size
-    16.  -> (rows [world, max_nnz], offsets [world, nql + 1], narrow, small_off, handle, handle)"""
+    16.  -> (rows [world, max_nnz], offsets [world, nql + 1], narrow, small_off, handle, handle); the handles hold the
+    send buffers until they are waited for."""
     dev = offsets.device
     cnt = torch.empty((world,), dtype=torch.int64, device=dev)
     _all_gather(cnt, torch.tensor([rows.numel()], dtype=torch.int64, device=dev), group)
     max_nnz = max(1, int(cnt.max().item()))
     rows_pad = rows if rows.numel() == max_nnz else torch.cat([rows, rows.new_zeros(max_nnz - rows.numel())])
-    bg = background_group(group)
+    bg = background_group(group, force)
     narrow = table.D <= 65536
     small_off = max_nnz < (1 << 31)
     rows_w = rows_pad.to(torch.int16) if narrow else rows_pad
     off_w = offsets.to(torch.int32) if small_off else offsets
     ra_w = torch.empty((world, max_nnz), dtype=rows_w.dtype, device=dev)
     oa_w = torch.empty((world, nql + 1), dtype=off_w.dtype, device=dev)
-    h_r = _all_gather(ra_w, rows_w.view(1, -1), bg, async_op=True)
-    h_o = _all_gather(oa_w, off_w.view(1, -1), bg, async_op=True)
+    h_r = _Pending(_all_gather(ra_w, rows_w.view(1, -1), bg, async_op=True), rows_w, rows_pad)
+    h_o = _Pending(_all_gather(oa_w, off_w.view(1, -1), bg, async_op=True), off_w)
     ph.sent("0_answer_sets", (rows_w.numel() * rows_w.element_size() + off_w.numel() * off_w.element_size()) * (world - 1))
     return ra_w, oa_w, narrow, small_off, h_r, h_o
 
 
 def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="all_to_all", backend=None,
-                               group=None, wide_ids=None, sig_exchange="auto", phases=None, local_dedup=None):
+                               group=None, wide_ids=None, sig_exchange="auto", phases=None, local_dedup=None,
+                               force_collectives=False):
     """Hot path for this rank's query shard (the queries shard_range(nq_total, world, rank) names);
     collective over `group`.  Returns a HotPathResult: sig / norm2 / top-K rows of this rank's queries
     (global ids; concatenated over ranks in rank order they equal the single-GPU result) and the
     candidate pairs this rank scored, sorted (disjoint over ranks; their union is the single-GPU list).
     phases: a dict that accumulates "ms:<phase>" / "bytes:<collective>" over calls (diagnostics).
-    local_dedup: de-duplicate the rank's own emissions before the pair exchange (None: up to four ranks)."""
+    local_dedup: de-duplicate the rank's own emissions before the pair exchange (None: up to four ranks).
+    force_collectives: with ONE rank, go through every exchange step (collectives that send a rank's data to
+    itself, the second communicator, the remote-row machinery over an empty remote set) instead of the one-rank
+    short cuts -- a one-GPU box then makes RCCL execute every collective shape the N-rank step issues."""
     be = backend if backend is not None else HipBackend()
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
@@ -344,6 +364,7 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
     dev = offsets.device
     stats = {}
     ph = _Phases(phases, dev)
+    multi = world > 1 or bool(force_collectives)      # take the exchange steps
 
     if sig_exchange == "auto":
         # few ranks = few links, and everything a rank sends to one peer crosses ONE of them: up to four ranks the
@@ -356,9 +377,10 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
     lo, hi = ranges[rank]
     nb = hi - lo
     keys_all = None
-    if sig_exchange == "recompute" and world > 1:
+    if sig_exchange == "recompute" and multi:
         # 0. answer sets of every shard: the offsets (nql + 1 each) and the row ids, padded to the largest shard
-        ra_w, oa_w, narrow, small_off, h_r, h_o = _gather_answer_sets(offsets, rows, table, nql, world, group, ph)
+        ra_w, oa_w, narrow, small_off, h_r, h_o = _gather_answer_sets(offsets, rows, table, nql, world, group, ph,
+                                                                      force_collectives)
         # 1. signatures of ALL queries, own shard first (it runs beside the gather); every block goes straight to
         #    its place in the replicated tables when the row blocks keep the kernel's 16-byte alignment
         sdt = be.sig_dtype(table)
@@ -392,9 +414,9 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
         stats["bucket_id_exchange"] = "none (answer sets replicated)"
     else:
         sets = None
-        if sig_exchange == "sets" and world > 1:
+        if sig_exchange == "sets" and multi:
             # 0'. the same gather, in the background: what it brings is first needed at step 5
-            sets = _gather_answer_sets(offsets, rows, table, nql, world, group, ph)
+            sets = _gather_answer_sets(offsets, rows, table, nql, world, group, ph, force_collectives)
         # 1. local signatures
         sig, norm2, keys = be.minhash(offsets, rows, table, b)
     ph.done("1_minhash")
@@ -402,7 +424,7 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
     # 2. bucket-id exchange (short, needed at once: issued before the long gather)
     if keys_all is not None:
         recv = owned = None
-    elif world == 1:
+    elif not multi:
         recv, owned = keys, None  # nothing to exchange: the local keys are the [1][b][nql] buffer
     elif exchange == "all_gather":
         allk = torch.empty((world * b, nql), dtype=torch.int64, device=dev)
@@ -423,11 +445,12 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
     gathered = None
     if keys_all is not None:
         gathered = (sa, na, _Done(), _Done())
-    elif sig_exchange == "all_gather":
-        bg = background_group(group)
+    elif sig_exchange == "all_gather" and multi:
+        bg = background_group(group, force_collectives)
         sa = torch.empty((nids, P), dtype=sig.dtype, device=dev)
         na = torch.empty((nids,), dtype=torch.int64, device=dev)
-        gathered = (sa, na, _all_gather(sa, sig, bg, async_op=True), _all_gather(na, norm2, bg, async_op=True))
+        gathered = (sa, na, _Pending(_all_gather(sa, sig, bg, async_op=True), sig),
+                    _Pending(_all_gather(na, norm2, bg, async_op=True), norm2))
         ph.sent("5_signature_rows", (sig.numel() * sig.element_size() + norm2.numel() * 8) * (world - 1))
     stats["sig_exchange"] = sig_exchange
 
@@ -449,10 +472,10 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
     #    (375 -> ~140 MB out per rank and step at two ranks, 10 M queries)
     if local_dedup is None:
         local_dedup = 1 < world <= 4
-    if world > 1 and local_dedup and emitted.numel():
+    if multi and local_dedup and emitted.numel():
         emitted = be.sort_unique(emitted, nids, words_per_query=emitted.numel() / max(1, nids))
         stats["local_unique_pairs"] = int(emitted.numel())
-    if world > 1:
+    if multi:
         mine, bounds = be.group_pairs_by_host(emitted, nql, world)
         ssz, rsz = _exchange_sizes(bounds, group)
         got = torch.empty((sum(rsz),), dtype=torch.int64, device=dev)
@@ -474,7 +497,7 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
         h_sig.wait()
         h_nrm.wait()
         score_sig, score_norm, local_pairs = sa, na, pairs          # row index == global query id
-    elif world == 1:
+    elif not multi:
         score_sig, score_norm, local_pairs = sig, norm2, pairs
         stats["remote_rows_fetched"] = 0
     elif sig_exchange == "sets":
@@ -524,7 +547,7 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
     del local_pairs, sig_b, norm_b, gathered
     ph.done("6_score")
     ek, ed = be.edges(pairs, milli, ib, wide)
-    if world > 1:
+    if multi:
         klo = 11 if wide else ib + 11
         ek, ed, bounds = be.group_edges_by_owner(ek, ed, klo, nql, world)
         ssz, rsz = _exchange_sizes(bounds, group)
@@ -545,7 +568,7 @@ def query_similarities_sharded(offsets, rows, table, b, K, nq_total, exchange="a
     ph.done("7_topk")
     stats["unique_pairs"] = int(pairs.numel())
     stats["kept_edges"] = int(src.numel())
-    stats["topk"] = "select (received edges = reverse words, sorted on their src bits)" if world > 1 else "sort-stable"
+    stats["topk"] = "select (received edges = reverse words, sorted on their src bits)" if multi else "sort-stable"
     stats.update(getattr(be, "stats", {}))
     ph.close()
     return HotPathResult(sig[:n_real], norm2[:n_real], pairs, milli, src, dst, val, K, b, stats)

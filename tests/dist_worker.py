@@ -228,6 +228,7 @@ def main():
     out_dir, nq, D, P, b, mode = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
     extra = sys.argv[7:]
     wide = "wide" in extra
+    force = "force" in extra     # one rank through every exchange step (qrlsh.dist force_collectives)
     sig_mode = ([e[4:] for e in extra if e.startswith("sig=")] or ["auto"])[0]
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -236,7 +237,8 @@ def main():
     perms = O.legacy_permutations(42, P, D)
     off, rows = O.synth_csr(nq, D, seed=3, cluster=4, mean=6.0, q0=q0, nq_local=n_real)
     res = qdist.query_similarities_sharded(_t(off), _t(rows), OracleTable(perms), b, K, nq, exchange=mode,
-                                           backend=OracleBackend(), wide_ids=wide or None, sig_exchange=sig_mode)
+                                           backend=OracleBackend(), wide_ids=wide or None, sig_exchange=sig_mode,
+                                           force_collectives=force, local_dedup=True if force else None)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), sig=res.sig.numpy(), pairs=res.pairs.numpy(),
              milli=res.milli.numpy(), src=res.src.numpy(), dst=res.dst.numpy(), val=res.val.numpy(),
              emitted=res.stats["emitted_pairs"], sig_exchange=res.stats["sig_exchange"],

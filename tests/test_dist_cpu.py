@@ -41,7 +41,13 @@ def _run(tmp_path, world, nq, D, P, b, mode, port, extra=()):
                                                   (8, "all_to_all", 8, ("sig=fetch",), 603),        # the driver's N = 8:
                                                   (8, "all_to_all", 32, ("sig=fetch",), 1001),      # one band / four bands per rank
                                                   (2, "all_to_all", 4, ("wide", "sig=fetch"), 600),
-                                                  (2, "all_to_all", 4, ("wide", "sig=all_gather"), 599)])
+                                                  (2, "all_to_all", 4, ("wide", "sig=all_gather"), 599),
+                                                  # ONE rank made to take every exchange step (force_collectives: what
+                                                  # the -m gpu RCCL rehearsal runs with nccl on the one-GPU box)
+                                                  (1, "all_to_all", 8, ("force", "sig=sets"), 600),
+                                                  (1, "all_gather", 8, ("force", "sig=fetch"), 600),
+                                                  (1, "all_to_all", 8, ("force", "sig=recompute"), 600),
+                                                  (1, "all_to_all", 4, ("force", "wide", "sig=all_gather"), 600)])
 def test_sharded_equals_single_process(tmp_path, world, mode, b, extra, nq):
     # b = 4 with P = 32 is a wide band (r = 8: hashed bucket ids + verification); "wide" forces the
     # key + payload edge format used when two ids + 11 score bits do not fit 64 bits

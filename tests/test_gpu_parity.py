@@ -708,6 +708,26 @@ def test_sharded_driver_on_gpu_equals_single_gpu(tmp_path, world, mode, backend,
     _check_sharded_against(outs, res, nq, world)
 
 
+def test_rccl_executes_every_collective_shape_at_world_1():
+    """RCCL (backend "nccl") on the one GPU of this box: every collective shape the N-rank step issues -- variable
+    all-to-all with split lists (int64 / int32 / int16 rows as a 2-D byte view / empty), the size exchange, synchronous
+    and asynchronous all-gathers on the second communicator -- moves the right bytes, and the sharded driver with
+    force_collectives=True (no one-rank short cut: bucket-id exchange, pair hosting exchange, remote-row machinery,
+    edge exchange, received-edge top-K) equals the one-GPU pipeline bit for bit in every exchange / signature mode,
+    at 40 k and at 1 M queries (tests/dist_nccl_worker.py; N > 1 needs more GPUs than this pool hands out)."""
+    import subprocess
+    import sys as _sys
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29655",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    p = subprocess.run([_sys.executable, os.path.join(root, "tests", "dist_nccl_worker.py"), "40000", "1000000"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "RCCL_WORLD1_OK" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
+    assert p.stdout.count("forced world-1 step ok") == 10 and "collective shapes ok" in p.stdout
+
+
 def test_sharded_driver_retries_a_too_small_pair_buffer(tmp_path):
     """the one-pass emit sizes its output from what the last call of the shape produced (ops._EMIT_HINT); a
     guess that is far too small (here: 16 pairs, on every rank) must cost a second, exactly sized run and
