@@ -53,7 +53,8 @@ def parse():
     ap.add_argument("--drows", type=int, default=32768)
     ap.add_argument("--cpu-sample", type=int, default=-1,
                     help="queries in the CPU-baseline sample (-1 = the whole workload up to 10 M, 0 = skip)")
-    ap.add_argument("--cpu-threads", type=int, default=16, help="OpenMP threads of the CPU baseline (box share: 16/GPU)")
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="OpenMP threads of the CPU baseline (0 = every host core this process may run on)")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--prof-every", type=int, default=5,
                     help="bracket the kernels of every Nth timed step with HIP events (1 = every step; the events "
@@ -316,7 +317,7 @@ def main():
                  P=P, b=b, nnz=nnz, emitted=int(res.stats.get("emitted_pairs", 0)), unique=int(res.pairs.numel()),
                  kept=int(res.src.numel()), sig_bytes=2 if res.sig.dtype == torch.int16 else 4,
                  group_bits=int(res.stats.get("group_bits", 0)), part_bits=int(res.stats.get("part_bits", 8)),
-                 topk=("sort" if sharded and world > 1 else res.stats.get("topk", "select")))
+                 topk=("select" if sharded and world > 1 else res.stats.get("topk", "select")))
         ab = algorithmic_bytes_per_step(w)
         sb_tab = 2 if D <= 65536 else 4
         traffic, traffic_src, traffic_why = load_traffic(nq_total, P, b) if not sharded else ({}, None, "N > 1")
@@ -573,6 +574,23 @@ def secondary_figures(dev, table, P, b, D):
     return out
 
 
+def host_cores():
+    """(cores this process may be scheduled on, cgroup CPU quota in cores or None when unlimited)"""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        if q != "max":
+            quota = round(int(q) / int(per), 2)
+    except (OSError, ValueError):
+        pass
+    return avail, quota
+
+
 def cpu_leg(nq_s, nq_total, D, P, b, dev, threads, res_full, table):
     """CPU baseline (oracle = a C port of the reference's algorithm, OpenMP) on a bounded
     sample of the same workload, and recall@10 of the GPU path against it."""
@@ -585,11 +603,9 @@ def cpu_leg(nq_s, nq_total, D, P, b, dev, threads, res_full, table):
     K = pipeline.max_candidates(nq_s)
     perms = ops.legacy_permutations(P, D, seed=42)
     ho, hr = O.synth_csr(nq_s, D, seed=0)
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    cores = max(1, min(threads, avail))
+    avail, quota = host_cores()
+    usable = avail if quota is None else max(1, min(avail, int(quota + 0.5)))
+    cores = usable if threads <= 0 else max(1, min(threads, avail))
     O.set_threads(cores)
     O.query_similarities(ho[:2001], hr[:ho[2000]], D, P, b, K, 42)  # warm the library / threads
     t0 = time.perf_counter()
@@ -629,7 +645,8 @@ def cpu_leg(nq_s, nq_total, D, P, b, dev, threads, res_full, table):
     t5 = time.perf_counter()
     O.set_threads(cores)
     base = {
-        "value": round(nq_s / total, 1), "unit": "signatures/s", "cores": cores, "kind": "port",
+        "value": round(nq_s / total, 1), "unit": "signatures/s", "cores": cores, "cores_available": avail,
+        "cgroup_cpu_quota": quota, "kind": "port",
         "single_thread": {"value": round(n1 / (t5 - t4), 1), "unit": "signatures/s", "cores": 1,
                           "sample": "whole hot path on nq=%d, 1 thread" % n1, "seconds": round(t5 - t4, 3)},
         "sample": "whole hot path on nq=%d queries of the same synthetic recipe (P=%d, b=%d, D=%d)%s, oracle/qr_oracle.c "

@@ -148,6 +148,109 @@ static void radix_sort_u64(uint64_t *a, int64_t n) {
 }
 
 /* ------------------------------------------------------------------------
+ * Parallel helpers of the candidate stage (so that the all-core CPU baseline is not gated by one thread):
+ * words / records are dealt into NB buckets by a counting pass over per-thread chunks, then the buckets are
+ * worked independently under OpenMP.
+ * ---------------------------------------------------------------------- */
+static inline uint64_t oracle_mix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+static int bucket_bits_for(int64_t n, int64_t per_bucket, int max_bits) {
+  int bits = 0;
+  while (bits < max_bits && (n >> bits) > per_bucket) ++bits;
+  return bits;
+}
+
+/* sort + unique of n 64-bit words on all cores: the words are dealt into 2^bits ranges of their top `top_bits`
+ * significant bits (a counting pass per thread chunk), every range is radix-sorted and de-duplicated by one thread,
+ * the ranges are closed up.  The result is the sorted unique array (in `a`, count returned) -- what one serial
+ * radix sort + unique gives. */
+static int64_t parallel_sort_unique_u64(uint64_t *a, int64_t n) {
+  if (n < 2) return n;
+  uint64_t maxw = 0;
+#pragma omp parallel for reduction(max : maxw) schedule(static)
+  for (int64_t i = 0; i < n; ++i) maxw = a[i] > maxw ? a[i] : maxw;
+  int sig_bits = 0;
+  while (sig_bits < 64 && (maxw >> sig_bits) != 0) ++sig_bits;
+  int bits = bucket_bits_for(n, 1 << 15, 14);
+  if (bits > sig_bits) bits = sig_bits;
+  if (bits == 0) {
+    radix_sort_u64(a, n);
+    int64_t u = 0;
+    for (int64_t i = 0; i < n; ++i)
+      if (i == 0 || a[i] != a[i - 1]) a[u++] = a[i];
+    return u;
+  }
+  const int shift = sig_bits - bits;
+  const int64_t NB = (int64_t)1 << bits;
+  const int nt = qro_max_threads();
+  int64_t *cnt = (int64_t *)calloc((size_t)nt * (size_t)NB, sizeof(int64_t));
+  int64_t *bstart = (int64_t *)malloc((size_t)(NB + 1) * sizeof(int64_t));
+  int64_t *bcount = (int64_t *)malloc((size_t)NB * sizeof(int64_t));
+  uint64_t *tmp = (uint64_t *)malloc((size_t)n * sizeof(uint64_t));
+#pragma omp parallel num_threads(nt)
+  {
+#ifdef _OPENMP
+    const int tid = omp_get_thread_num(), nth = omp_get_num_threads();
+#else
+    const int tid = 0, nth = 1;
+#endif
+    const int64_t lo = n * tid / nth, hi = n * (tid + 1) / nth;
+    int64_t *c = cnt + (size_t)tid * NB;
+    for (int64_t i = lo; i < hi; ++i) c[a[i] >> shift]++;
+#pragma omp barrier
+#pragma omp single
+    {
+      int64_t run = 0;
+      for (int64_t q = 0; q < NB; ++q) {
+        bstart[q] = run;
+        for (int t = 0; t < nth; ++t) {
+          const int64_t v = cnt[(size_t)t * NB + q];
+          cnt[(size_t)t * NB + q] = run;
+          run += v;
+        }
+      }
+      bstart[NB] = run;
+    }
+    for (int64_t i = lo; i < hi; ++i) tmp[c[a[i] >> shift]++] = a[i];
+#pragma omp barrier
+#pragma omp for schedule(dynamic, 4)
+    for (int64_t q = 0; q < NB; ++q) {
+      uint64_t *w = tmp + bstart[q];
+      const int64_t m = bstart[q + 1] - bstart[q];
+      radix_sort_u64(w, m);
+      int64_t u = 0;
+      for (int64_t i = 0; i < m; ++i)
+        if (i == 0 || w[i] != w[i - 1]) w[u++] = w[i];
+      bcount[q] = u;
+    }
+  }
+  int64_t total = 0;
+  for (int64_t q = 0; q < NB; ++q) { const int64_t u = bcount[q]; bcount[q] = total; total += u; }
+#pragma omp parallel for schedule(dynamic, 16)
+  for (int64_t q = 0; q < NB; ++q) {
+    const int64_t u = (q + 1 < NB ? bcount[q + 1] : total) - bcount[q];
+    if (u) memcpy(a + bcount[q], tmp + bstart[q], (size_t)u * sizeof(uint64_t));
+  }
+  free(tmp); free(cnt); free(bstart); free(bcount);
+  return total;
+}
+
+/* growable per-thread pair buffers */
+typedef struct { uint64_t *p; int64_t n, cap; } pvec_t;
+static inline void pvec_reserve(pvec_t *v, int64_t extra) {
+  const int64_t need = v->n + extra;
+  if (need <= v->cap) return;
+  int64_t nc = v->cap ? v->cap : 1024;
+  while (nc < need) nc *= 2;
+  v->p = (uint64_t *)realloc(v->p, (size_t)nc * sizeof(uint64_t));
+  v->cap = nc;
+}
+
+/* ------------------------------------------------------------------------
  * a3. Candidate pairs -- lsh.py:40-55.
  *
  * For every band, every bucket with more than one member whose key is not the
@@ -155,6 +258,10 @@ static void radix_sort_u64(uint64_t *a, int64_t n) {
  * insertion (= query id) order so each pair is (i, j) with i < j; the Python set
  * removes duplicates across bands (:41, :53).  The `reversed(c) in candidates`
  * test (:52) compares an iterator object and is always False.
+ *
+ * All cores: per band the (key, id) records are dealt into hash ranges of the key (equal keys share a range), the
+ * ranges are sorted and their buckets' combinations written into per-thread buffers by independent threads; the
+ * emitted words are then sorted + de-duplicated range-parallel (parallel_sort_unique_u64).
  *
  * Output: *pairs_out = malloc'ed sorted unique array of (i << 32 | j); returns the
  * count, or -1 on bad arguments.  Free with qro_free.
@@ -164,62 +271,91 @@ QRO_API int64_t qro_candidates(const uint64_t *keys, int64_t nq, int32_t b, int3
   *pairs_out = NULL;
   if (nq < 0 || b <= 0 || r <= 0 || r > 4) return -1;
   const uint64_t ek = empty_key(r);
-  int nthreads = qro_max_threads();
-  uint64_t **tp = (uint64_t **)calloc((size_t)nthreads, sizeof(uint64_t *));
-  int64_t *tn = (int64_t *)calloc((size_t)nthreads, sizeof(int64_t));
-  int64_t *tc = (int64_t *)calloc((size_t)nthreads, sizeof(int64_t));
+  const int nt = qro_max_threads();
+  pvec_t *tv = (pvec_t *)calloc((size_t)nt, sizeof(pvec_t));
+  const int bits = bucket_bits_for(nq, 1 << 13, 16);
+  const int64_t NB = (int64_t)1 << bits;
+  rec_t *rec = (rec_t *)malloc((size_t)(nq > 0 ? nq : 1) * sizeof(rec_t));
+  int64_t *cnt = (int64_t *)malloc((size_t)nt * (size_t)NB * sizeof(int64_t));
+  int64_t *bstart = (int64_t *)malloc((size_t)(NB + 1) * sizeof(int64_t));
 
-#pragma omp parallel
-  {
+  for (int32_t band = 0; band < b; ++band) {
+#pragma omp parallel num_threads(nt)
+    {
 #ifdef _OPENMP
-    int tid = omp_get_thread_num();
+      const int tid = omp_get_thread_num(), nth = omp_get_num_threads();
 #else
-    int tid = 0;
+      const int tid = 0, nth = 1;
 #endif
-    rec_t *rec = (rec_t *)malloc((size_t)(nq > 0 ? nq : 1) * sizeof(rec_t));
-#pragma omp for schedule(dynamic, 1)
-    for (int32_t band = 0; band < b; ++band) {
-      for (int64_t q = 0; q < nq; ++q) {
-        rec[q].key = keys[(size_t)q * b + band];
-        rec[q].id = (uint32_t)q;
-      }
-      qsort(rec, (size_t)nq, sizeof(rec_t), cmp_rec);
-      int64_t s = 0;
-      while (s < nq) {
-        int64_t e = s + 1;
-        while (e < nq && rec[e].key == rec[s].key) ++e;
-        int64_t m = e - s;
-        if (m > 1 && rec[s].key != ek) {
-          int64_t need = tn[tid] + m * (m - 1) / 2;
-          if (need > tc[tid]) {
-            int64_t nc = tc[tid] ? tc[tid] : 1024;
-            while (nc < need) nc *= 2;
-            tp[tid] = (uint64_t *)realloc(tp[tid], (size_t)nc * sizeof(uint64_t));
-            tc[tid] = nc;
+      const int64_t lo = nq * tid / nth, hi = nq * (tid + 1) / nth;
+      int64_t *c = cnt + (size_t)tid * NB;
+      memset(c, 0, (size_t)NB * sizeof(int64_t));
+      if (bits)
+        for (int64_t q = lo; q < hi; ++q) c[oracle_mix64(keys[(size_t)q * b + band]) >> (64 - bits)]++;
+      else
+        c[0] = hi - lo;
+#pragma omp barrier
+#pragma omp single
+      {
+        int64_t run = 0;
+        for (int64_t k = 0; k < NB; ++k) {
+          bstart[k] = run;
+          for (int t = 0; t < nth; ++t) {
+            const int64_t v = cnt[(size_t)t * NB + k];
+            cnt[(size_t)t * NB + k] = run;
+            run += v;
           }
-          for (int64_t x = s; x < e; ++x)
-            for (int64_t y = x + 1; y < e; ++y)
-              tp[tid][tn[tid]++] = ((uint64_t)rec[x].id << 32) | rec[y].id;
         }
-        s = e;
+        bstart[NB] = run;
+      }
+      for (int64_t q = lo; q < hi; ++q) {
+        const uint64_t key = keys[(size_t)q * b + band];
+        rec_t *d = &rec[c[bits ? oracle_mix64(key) >> (64 - bits) : 0]++];
+        d->key = key;
+        d->id = (uint32_t)q;
+      }
+#pragma omp barrier
+      pvec_t *v = &tv[tid];
+#pragma omp for schedule(dynamic, 4)
+      for (int64_t k = 0; k < NB; ++k) {
+        rec_t *w = rec + bstart[k];
+        const int64_t m_all = bstart[k + 1] - bstart[k];
+        if (m_all < 2) continue;
+        qsort(w, (size_t)m_all, sizeof(rec_t), cmp_rec);
+        int64_t s = 0;
+        while (s < m_all) {
+          int64_t e = s + 1;
+          while (e < m_all && w[e].key == w[s].key) ++e;
+          const int64_t m = e - s;
+          if (m > 1 && w[s].key != ek) {
+            pvec_reserve(v, m * (m - 1) / 2);
+            uint64_t *o = v->p + v->n;
+            for (int64_t x = s; x < e; ++x)
+              for (int64_t y = x + 1; y < e; ++y) *o++ = ((uint64_t)w[x].id << 32) | w[y].id;
+            v->n += m * (m - 1) / 2;
+          }
+          s = e;
+        }
       }
     }
-    free(rec);
   }
+  free(rec); free(cnt); free(bstart);
   int64_t total = 0;
-  for (int t = 0; t < nthreads; ++t) total += tn[t];
+  for (int t = 0; t < nt; ++t) total += tv[t].n;
   uint64_t *all = (uint64_t *)malloc((size_t)(total > 0 ? total : 1) * sizeof(uint64_t));
   int64_t o = 0;
-  for (int t = 0; t < nthreads; ++t) {
-    if (tn[t]) memcpy(all + o, tp[t], (size_t)tn[t] * sizeof(uint64_t));
-    o += tn[t];
-    free(tp[t]);
+  for (int t = 0; t < nt; ++t) {          /* (copies run in parallel: each thread's buffer has its own place) */
+    const int64_t at = o;
+    o += tv[t].n;
+    tv[t].cap = at;
   }
-  free(tp); free(tn); free(tc);
-  radix_sort_u64(all, total);
-  int64_t u = 0;
-  for (int64_t i = 0; i < total; ++i)
-    if (i == 0 || all[i] != all[i - 1]) all[u++] = all[i];
+#pragma omp parallel for schedule(static, 1)
+  for (int t = 0; t < nt; ++t) {
+    if (tv[t].n) memcpy(all + tv[t].cap, tv[t].p, (size_t)tv[t].n * sizeof(uint64_t));
+    free(tv[t].p);
+  }
+  free(tv);
+  const int64_t u = parallel_sort_unique_u64(all, total);
   *pairs_out = all;
   return u;
 }
@@ -280,10 +416,7 @@ QRO_API int64_t qro_candidates_from_sig(const int32_t *sig, int64_t nq, int32_t 
   }
   free(idx);
   if (!all) all = (uint64_t *)malloc(sizeof(uint64_t));
-  radix_sort_u64(all, n);
-  int64_t u = 0;
-  for (int64_t i = 0; i < n; ++i)
-    if (i == 0 || all[i] != all[i - 1]) all[u++] = all[i];
+  const int64_t u = parallel_sort_unique_u64(all, n);
   *pairs_out = all;
   return u;
 }
@@ -377,52 +510,89 @@ static int cmp_k2(const void *a, const void *b) {
 QRO_API int64_t qro_topk(const uint64_t *pairs, const int32_t *milli, int64_t n, int32_t K,
                          int32_t *src, int32_t *dst, int32_t *val) {
   /* sortable 16-byte records: hi = src << 32 | (2000 - (milli + 1000)), lo = dst.  The records are
-   * first dealt into NB ranges of src (counting pass), the ranges sorted independently (OpenMP), so
-   * the whole array ends up in (src, inv, dst) order -- same result as one qsort, on all cores. */
+   * first dealt into NB ranges of src (a counting pass per thread chunk), the ranges sorted independently (OpenMP),
+   * so the whole array ends up in (src, inv, dst) order -- same result as one qsort (the records are distinct), on
+   * all cores; the cut to K per src is made per range (a src never straddles two ranges) and written in place. */
   const int64_t m = 2 * n;
   k2_t *k = (k2_t *)malloc((size_t)(m > 0 ? m : 1) * sizeof(k2_t));
   uint32_t maxid = 0;
+#pragma omp parallel for reduction(max : maxid) schedule(static)
   for (int64_t t = 0; t < n; ++t) {
     uint32_t j = (uint32_t)(pairs[t] & 0xFFFFFFFFu); /* i < j */
     if (j > maxid) maxid = j;
   }
   enum { NB = 4096 };
   const uint64_t span = (uint64_t)maxid + 1;
+  const int nt = qro_max_threads();
   int64_t *start = (int64_t *)calloc(NB + 1, sizeof(int64_t));
-  for (int64_t t = 0; t < n; ++t) {
-    uint32_t i = (uint32_t)(pairs[t] >> 32), j = (uint32_t)(pairs[t] & 0xFFFFFFFFu);
-    start[(uint64_t)i * NB / span + 1]++;
-    start[(uint64_t)j * NB / span + 1]++;
-  }
-  for (int q = 0; q < NB; ++q) start[q + 1] += start[q];
-  int64_t *cur = (int64_t *)malloc(NB * sizeof(int64_t));
-  memcpy(cur, start, NB * sizeof(int64_t));
-  for (int64_t t = 0; t < n; ++t) {
-    uint32_t i = (uint32_t)(pairs[t] >> 32), j = (uint32_t)(pairs[t] & 0xFFFFFFFFu);
-    uint32_t inv = (uint32_t)(1000 - milli[t]); /* milli in [-1000, 1000] -> inv in [0, 2000] */
-    k2_t *a = &k[cur[(uint64_t)i * NB / span]++], *c = &k[cur[(uint64_t)j * NB / span]++];
-    a->hi = ((uint64_t)i << 32) | inv; a->lo = j;
-    c->hi = ((uint64_t)j << 32) | inv; c->lo = i;
-  }
-#pragma omp parallel for schedule(dynamic, 8)
-  for (int q = 0; q < NB; ++q)
-    if (start[q + 1] - start[q] > 1) qsort(k + start[q], (size_t)(start[q + 1] - start[q]), sizeof(k2_t), cmp_k2);
-  free(cur);
-  free(start);
-  int64_t out = 0, run = 0;
-  uint32_t cs = 0;
-  for (int64_t t = 0; t < m; ++t) {
-    uint32_t s = (uint32_t)(k[t].hi >> 32);
-    if (t == 0 || s != cs) { cs = s; run = 0; }
-    if (run < K) {
-      src[out] = (int32_t)s;
-      dst[out] = (int32_t)k[t].lo;
-      val[out] = 1000 - (int32_t)(uint32_t)(k[t].hi & 0xFFFFFFFFu);
-      ++out;
+  int64_t *cnt = (int64_t *)calloc((size_t)nt * NB, sizeof(int64_t));
+  int64_t *kept = (int64_t *)calloc(NB + 1, sizeof(int64_t));
+#pragma omp parallel num_threads(nt)
+  {
+#ifdef _OPENMP
+    const int tid = omp_get_thread_num(), nth = omp_get_num_threads();
+#else
+    const int tid = 0, nth = 1;
+#endif
+    const int64_t lo = n * tid / nth, hi = n * (tid + 1) / nth;
+    int64_t *c = cnt + (size_t)tid * NB;
+    for (int64_t t = lo; t < hi; ++t) {
+      uint32_t i = (uint32_t)(pairs[t] >> 32), j = (uint32_t)(pairs[t] & 0xFFFFFFFFu);
+      c[(uint64_t)i * NB / span]++;
+      c[(uint64_t)j * NB / span]++;
     }
-    ++run;
+#pragma omp barrier
+#pragma omp single
+    {
+      int64_t run = 0;
+      for (int q = 0; q < NB; ++q) {
+        start[q] = run;
+        for (int t = 0; t < nth; ++t) {
+          const int64_t v = cnt[(size_t)t * NB + q];
+          cnt[(size_t)t * NB + q] = run;
+          run += v;
+        }
+      }
+      start[NB] = run;
+    }
+    for (int64_t t = lo; t < hi; ++t) {
+      uint32_t i = (uint32_t)(pairs[t] >> 32), j = (uint32_t)(pairs[t] & 0xFFFFFFFFu);
+      uint32_t inv = (uint32_t)(1000 - milli[t]); /* milli in [-1000, 1000] -> inv in [0, 2000] */
+      k2_t *a = &k[c[(uint64_t)i * NB / span]++], *e = &k[c[(uint64_t)j * NB / span]++];
+      a->hi = ((uint64_t)i << 32) | inv; a->lo = j;
+      e->hi = ((uint64_t)j << 32) | inv; e->lo = i;
+    }
+#pragma omp barrier
+#pragma omp for schedule(dynamic, 8)
+    for (int q = 0; q < NB; ++q) {
+      k2_t *w = k + start[q];
+      const int64_t len = start[q + 1] - start[q];
+      if (len > 1) qsort(w, (size_t)len, sizeof(k2_t), cmp_k2);
+      /* the cut: the first K records of every src, closed up at the front of the range */
+      int64_t out = 0, run = 0;
+      uint32_t cs = 0;
+      for (int64_t t = 0; t < len; ++t) {
+        uint32_t s = (uint32_t)(w[t].hi >> 32);
+        if (t == 0 || s != cs) { cs = s; run = 0; }
+        if (run < K) w[out++] = w[t];
+        ++run;
+      }
+      kept[q + 1] = out;
+    }
   }
-  free(k);
+  for (int q = 0; q < NB; ++q) kept[q + 1] += kept[q];
+#pragma omp parallel for schedule(dynamic, 8)
+  for (int q = 0; q < NB; ++q) {
+    const k2_t *w = k + start[q];
+    const int64_t at = kept[q], len = kept[q + 1] - kept[q];
+    for (int64_t t = 0; t < len; ++t) {
+      src[at + t] = (int32_t)(uint32_t)(w[t].hi >> 32);
+      dst[at + t] = (int32_t)w[t].lo;
+      val[at + t] = 1000 - (int32_t)(uint32_t)(w[t].hi & 0xFFFFFFFFu);
+    }
+  }
+  const int64_t out = kept[NB];
+  free(cnt); free(start); free(kept); free(k);
   return out;
 }
 
