@@ -48,6 +48,8 @@ def lib():
         L.qro_candidates_from_sig.restype = ctypes.c_int64
         L.qro_emitted_pairs.restype = ctypes.c_int64
         L.qro_topk.restype = ctypes.c_int64
+        L.qro_filter_pair_host.restype = ctypes.c_int64
+        L.qro_sort_unique_u64.restype = ctypes.c_int64
         L.qro_free.argtypes = [ctypes.c_void_p]
         _LIB = L
     return _LIB
@@ -151,6 +153,23 @@ def candidates_from_sig(sig, b):
     arr = np.ctypeslib.as_array(out, shape=(max(n, 1),))[:n].copy()
     lib().qro_free(out)
     return arr
+
+
+def filter_pair_host(pairs, shard, rank):
+    """the words of `pairs` (order kept) that rank `rank` of a sharded run scores: the owner (shards of `shard`
+    consecutive ids) of i or of j, picked by the top bit of mix64(pair) -- csrc/common.h: qr_pair_host"""
+    pairs = np.ascontiguousarray(pairs, dtype=np.uint64)
+    out = np.empty(len(pairs), dtype=np.uint64)
+    n = lib().qro_filter_pair_host(_p(pairs, c_u64p), ctypes.c_int64(len(pairs)), ctypes.c_uint32(shard),
+                                   ctypes.c_uint32(rank), _p(out, c_u64p))
+    return out[:n].copy()
+
+
+def sort_unique(words):
+    """sorted unique copy of a uint64 array (all cores)"""
+    a = np.array(words, dtype=np.uint64, copy=True)
+    n = lib().qro_sort_unique_u64(_p(a, c_u64p), ctypes.c_int64(len(a)))
+    return a[:n].copy()
 
 
 def emitted_pairs(keys, r):

@@ -360,6 +360,48 @@ QRO_API int64_t qro_candidates(const uint64_t *keys, int64_t nq, int32_t b, int3
   return u;
 }
 
+/* ------------------------------------------------------------------------
+ * Helpers of the large sharded tests (not part of the reference's algorithm): the words of a sorted pair list that
+ * a given rank of a sharded run scores -- the numpy twin tests/dist_worker.py:pair_host states the rule
+ * (csrc/common.h: qr_pair_host: the owner of i or of j, picked by the top bit of mix64(pair)) -- and the sorted
+ * union of word lists, both on all cores.
+ * ---------------------------------------------------------------------- */
+QRO_API int64_t qro_filter_pair_host(const uint64_t *pairs, int64_t n, uint32_t shard, uint32_t rank, uint64_t *out) {
+  const int nt = qro_max_threads();
+  int64_t *cnt = (int64_t *)calloc((size_t)nt + 1, sizeof(int64_t));
+#pragma omp parallel num_threads(nt)
+  {
+#ifdef _OPENMP
+    const int tid = omp_get_thread_num(), nth = omp_get_num_threads();
+#else
+    const int tid = 0, nth = 1;
+#endif
+    const int64_t lo = n * tid / nth, hi = n * (tid + 1) / nth;
+    int64_t c = 0;
+    for (int64_t t = lo; t < hi; ++t) {
+      const uint64_t w = pairs[t];
+      const uint64_t id = (oracle_mix64(w) >> 63) ? (w & 0xFFFFFFFFull) : (w >> 32);
+      c += id / shard == rank;
+    }
+    cnt[tid + 1] = c;
+#pragma omp barrier
+#pragma omp single
+    for (int t = 0; t < nth; ++t) cnt[t + 1] += cnt[t];
+    int64_t o = cnt[tid];
+    for (int64_t t = lo; t < hi; ++t) {
+      const uint64_t w = pairs[t];
+      const uint64_t id = (oracle_mix64(w) >> 63) ? (w & 0xFFFFFFFFull) : (w >> 32);
+      if (id / shard == rank) out[o++] = w;
+    }
+  }
+  int64_t total = 0;
+  for (int t = 0; t <= nt; ++t) total = cnt[t] > total ? cnt[t] : total;
+  free(cnt);
+  return total;
+}
+
+QRO_API int64_t qro_sort_unique_u64(uint64_t *a, int64_t n) { return parallel_sort_unique_u64(a, n); }
+
 /* Same as qro_candidates, for ANY band width r = P / b: buckets are grouped by comparing the
  * int16 tuples themselves (no 64-bit packing), straight from the signature matrix. */
 typedef struct { const int32_t *sig; int32_t P, off, r; } tuple_ctx_t;
