@@ -154,12 +154,19 @@ int qrlsh_bucket_pairs_fill(const uint64_t *part_keys, const uint32_t *part_ids,
  * oversized-part flag as qrlsh_bucket_pairs_count.  The pairs come out in no particular order.
  * part_keys / part_ids must hold qrlsh_bucket_part_words(nq, b, part_bits) words and, for part_bits > 8,
  * tmp_keys / tmp_ids qrlsh_bucket_tmp_words(...): the partition is ONE kernel per level (one level for
- * part_bits = 8, two of about part_bits / 2 bits each beyond) that gives every part a fixed region and reserves
- * room in it with an atomic per (tile, part) -- no histogram pass, no scan, no bounds search -- and those regions
- * need more room than the b * nq records themselves (a part outgrowing its region raises the same overflow
- * flag).  These buffers are scratch: what they hold afterwards is mix64(key) (a bijection of the keys, which is
- * all the pairing needs), not the keys, and the records of empty bands are gone. */
+ * part_bits = 8, two of about part_bits / 2 bits each beyond) that gives every part a fixed region of ONE LDS image
+ * of the finish and reserves room in it with an atomic per (tile, part) -- no histogram pass, no scan, no bounds
+ * search.  Behind the regions the same buffers hold an OVERFLOW POOL (1/16 of the records, at least 1 M): a part
+ * swollen by a popular key (lsh.py:42-49 makes a bucket of m queries m(m-1)/2 pairs whatever m is; at 100 M queries
+ * over 32768 table rows m reaches ~20 000) spills there and is worked in blocks of one image; only a part beyond
+ * qrlsh_set_big_part_limit records (default 16 images = 98 304), more than 4096 such parts per band group, or an
+ * exhausted pool raise the overflow flag.  Reserved: ~1.4 - 2 x the b * nq records.  These buffers are scratch:
+ * what they hold afterwards is mix64(key) (a bijection of the keys, which is all the pairing needs), not the keys,
+ * and the records of empty bands are gone. */
 size_t qrlsh_bucket_part_words(int64_t nq, int32_t b, int32_t part_bits);
+/* records a part beyond the LDS image may hold and stay on the partition path (<= 0 or beyond the maximum: the
+ * default, 98 304); returns the previous limit.  Process-wide; a tuning / test knob. */
+int64_t qrlsh_set_big_part_limit(int64_t records);
 size_t qrlsh_bucket_tmp_words(int64_t nq, int32_t b, int32_t part_bits);
 int qrlsh_bucket_pairs_emit(const uint64_t *keys, uint64_t *part_keys, uint32_t *part_ids,
                             uint64_t *tmp_keys, uint32_t *tmp_ids, int64_t nq, int32_t b, int32_t r,
@@ -281,6 +288,10 @@ int qrlsh_topk_fill_based(const uint64_t *sorted_edges, const uint32_t *sorted_d
 int qrlsh_score_pairs_rev(const void *sig, int32_t sig_dtype, const int64_t *norm2, int32_t P,
                           const uint64_t *pairs, int64_t n, int32_t *milli_out, uint64_t *rev_out, int32_t id_bits,
                           uint32_t *rev_dst_out, void *stream);
+/* 1 (default): compact rows of 128 / 256 values with precomputed norms are scored by the run form (16 consecutive pairs
+ * per 16-lane group, first row kept while it does not change); 0: by the generic form.  Same results bit for bit; an
+ * A/B and test knob.  Returns the previous setting (-1: not yet decided, i.e. the default). */
+int qrlsh_set_score_runs(int on);
 size_t qrlsh_topk_select_workspace_bytes(int64_t nq);
 int qrlsh_topk_select_count(const uint64_t *pairs, int64_t n, const uint64_t *rev_sorted, const uint32_t *rev_dst,
                             int64_t nq, int32_t K, int32_t id_bits, void *workspace, size_t workspace_bytes,

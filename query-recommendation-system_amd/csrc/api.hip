@@ -71,7 +71,9 @@ bool qr_prof_active() {
 // beside the caller's, so that a latency-bound kernel of one piece shares the device with a bandwidth-bound
 // kernel of the next.  Fork: the auxiliary stream waits for everything already queued on the caller's
 // stream; join: the caller's stream waits for the auxiliary one -- to the caller the entry point is still one
-// asynchronous call on its stream.  One auxiliary stream and two events per device, created on first use.
+// asynchronous call on its stream.  One auxiliary stream and two events PER DEVICE, created on first use: the overlap is
+// per device, not per caller stream -- concurrent callers on one device (the library's contract is one host thread
+// per device) would be serialised on it and see each other's work as dependencies; correct, never faster.
 namespace {
 struct Aux { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool ok = false, tried = false; };
 Aux g_aux[16];
@@ -105,14 +107,19 @@ hipStream_t qr_aux_fork(hipStream_t st) {
   return a.s;
 }
 
-void qr_aux_join(hipStream_t st) {
+// 0, or QRLSH_EHIP when the caller's stream could not be ordered after the auxiliary one: the auxiliary stream is then
+// drained on the host (whatever ran there is complete before the entry point returns) and the error is reported --
+// the call never returns OK with work of its own still unordered.
+int qr_aux_join(hipStream_t st) {
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return QRLSH_EHIP;
   std::lock_guard<std::mutex> lk(g_mu);
   Aux &a = g_aux[dev];
-  if (!a.ok) return;
-  (void)hipEventRecord(a.join, a.s);
-  (void)hipStreamWaitEvent(st, a.join, 0);
+  if (!a.ok) return QRLSH_OK;   // never forked
+  if (hipEventRecord(a.join, a.s) == hipSuccess && hipStreamWaitEvent(st, a.join, 0) == hipSuccess) return QRLSH_OK;
+  (void)hipStreamSynchronize(a.s);
+  qrlsh_set_error("auxiliary stream could not be joined to the caller's stream");
+  return QRLSH_EHIP;
 }
 
 QRLSH_EXPORT int qrlsh_prof_enable(int on) {

@@ -35,7 +35,7 @@ void qr_prof_end(int slot, hipStream_t st);
 
 // second stream for overlapping independent pieces of one call (api.hip); nullptr = run everything on `st`
 hipStream_t qr_aux_fork(hipStream_t st);
-void qr_aux_join(hipStream_t st);
+int qr_aux_join(hipStream_t st);
 
 #define QR_LAUNCH(label, kern, grid, block, smem, st, ...)               \
   do {                                                                   \

@@ -11,6 +11,8 @@
 // P * D^2 < 2^63), so the only rounding is the final divide -- within 2 ulp of sklearn's
 // normalise-then-multiply and identical after the rounding to 3 decimals (checked on every
 // golden pair).  HBM-bound: 2 * 4P bytes of rows per pair.
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -167,6 +169,169 @@ __global__ __launch_bounds__(256) void score_pairs_kernel(const SigT *__restrict
   }
 }
 
+// ---- the run form (round 4): compact uint16 rows of 128 or 256 values, precomputed norms ------------------------------
+// The candidate pairs are SORTED (i, j): consecutive pairs share their first row.  A 16-lane group (one DPP row) takes
+// 16 CONSECUTIVE pairs at a time instead of every ngroups-th one:
+//   * one coalesced 128-B load brings the group its 16 pair words, lane u holding pair u; both norms of pair u are
+//     loaded by lane u itself -- 3 vector-memory instructions per 64 pairs of a wave where the form above issues 3 per
+//     FOUR pairs;
+//   * row i stays in registers while i does not change (a new a-row is loaded for ~1 pair in 4 on the bench data);
+//   * the second row of pair u + PF is requested before pair u is summed (PF rows in flight per lane behind the
+//     arithmetic);
+//   * the 16-lane sum of a pair is a DPP all-reduce (two quad permutes, half-row mirror, row mirror: no LDS pipe) and
+//     lane u keeps pair u's total, so the float64 square roots, the divide and the rounding run ONCE per chunk on all
+//     64 lanes (one pair each) instead of per pair on 4 lanes of 64, and scores / edge words leave as whole lines.
+// Same integers, same float64 expression: bit-identical to score_pairs_kernel.  Pairs beyond n are computed on row 0
+// and never stored.
+template <int U> __device__ static inline uint32_t row_bcast_u32(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x150 + U, 0xF, 0xF, false);   // row_newbcast:U
+}
+template <int CTRL> __device__ static inline uint64_t dpp_add_u64(uint64_t v) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, 0xF, 0xF, false);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, 0xF, 0xF, false);
+  return v + (((uint64_t)hi << 32) | lo);
+}
+// sum over the 16 lanes of a DPP row, in every lane of the row
+__device__ static inline uint64_t row_sum_u64(uint64_t v) {
+  v = dpp_add_u64<0xB1>(v);   // quad_perm [1,0,3,2]
+  v = dpp_add_u64<0x4E>(v);   // quad_perm [2,3,0,1]
+  v = dpp_add_u64<0x141>(v);  // row_half_mirror
+  v = dpp_add_u64<0x140>(v);  // row_mirror
+  return v;
+}
+
+// exact dot product of two 8-value chunks of compact rows (see score_pairs_kernel)
+__device__ static inline uint64_t chunk_dot(u16x8 x, u16x8 y) {
+  const u32x4 xw = __builtin_bit_cast(u32x4, x), yw = __builtin_bit_cast(u32x4, y);
+  const uint32_t hi = (xw[0] | xw[1] | xw[2] | xw[3] | yw[0] | yw[1] | yw[2] | yw[3]) & 0x80008000u;
+  if (hi == 0) {
+    uint32_t s0 = __builtin_amdgcn_udot2(__builtin_shufflevector(x, x, 0, 1), __builtin_shufflevector(y, y, 0, 1), 0u, false);
+    uint32_t s1 = __builtin_amdgcn_udot2(__builtin_shufflevector(x, x, 2, 3), __builtin_shufflevector(y, y, 2, 3), 0u, false);
+    s0 = __builtin_amdgcn_udot2(__builtin_shufflevector(x, x, 4, 5), __builtin_shufflevector(y, y, 4, 5), s0, false);
+    s1 = __builtin_amdgcn_udot2(__builtin_shufflevector(x, x, 6, 7), __builtin_shufflevector(y, y, 6, 7), s1, false);
+    return (uint64_t)s0 + (uint64_t)s1;
+  }
+  int64_t d = 0;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) d += c16(x[e]) * c16(y[e]);
+  return (uint64_t)d;
+}
+
+#ifndef QR_SCORE_PF
+#define QR_SCORE_PF 2   // second rows requested ahead of the one being summed
+#endif
+constexpr int SCORE_PF = QR_SCORE_PF;
+
+#ifndef QR_SCORE_OCC
+#define QR_SCORE_OCC 8   // workgroups of 4 waves per CU the register budget is held to (8: 64 VGPRs)
+#endif
+template <int CH>
+__global__ __launch_bounds__(256, QR_SCORE_OCC) void score_runs_kernel(const uint16_t *__restrict__ sig, const int64_t *__restrict__ norm2,
+                                                         const uint64_t *__restrict__ pairs, int64_t n,
+                                                         int32_t *__restrict__ milli, double *__restrict__ cosv,
+                                                         uint64_t *__restrict__ edges, int id_bits,
+                                                         uint32_t *__restrict__ edge_dst,
+                                                         const uint16_t *__restrict__ sig_b,
+                                                         const int64_t *__restrict__ norm2_b, uint32_t split, int rev_only) {
+  constexpr int P = CH * 128;
+  constexpr int NB = SCORE_PF + 1;   // row buffers in rotation
+  const int lig = threadIdx.x & (SCORE_LPP - 1);
+  const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / SCORE_LPP;
+  const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) / SCORE_LPP;
+  const int64_t nchunks = (n + SCORE_LPP - 1) / SCORE_LPP;
+  auto row_of = [&](uint32_t id) -> const uint16_t * {
+    return (id < split ? sig + (size_t)id * P : sig_b + (size_t)(id - split) * P) + lig * 8;
+  };
+  auto load_row = [&](u16x8 (&dst)[CH], const uint16_t *p) {
+#pragma unroll
+    for (int k = 0; k < CH; ++k) dst[k] = *reinterpret_cast<const u16x8 *>(p + k * 128);
+  };
+  int64_t c = group;
+  uint64_t pw_next = (c < nchunks && c * SCORE_LPP + lig < n) ? pairs[c * SCORE_LPP + lig] : 0ull;
+  for (; c < nchunks; c += ngroups) {   // (a group's trip count is its own: nothing below crosses DPP rows)
+    const int64_t t = c * SCORE_LPP + lig;
+    const bool live = t < n;
+    const uint64_t pw = pw_next;
+    {
+      const int64_t cn = c + ngroups;
+      pw_next = (cn < nchunks && cn * SCORE_LPP + lig < n) ? pairs[cn * SCORE_LPP + lig] : 0ull;
+    }
+    const uint32_t my_i = (uint32_t)(pw >> 32), my_j = (uint32_t)pw;
+    int64_t na = 0, nb = 0;
+    if (live) {
+      na = my_i < split ? norm2[my_i] : norm2_b[my_i - split];
+      nb = my_j < split ? norm2[my_j] : norm2_b[my_j - split];
+    }
+    uint64_t my_dot = 0;
+    u16x8 a[CH], cb[NB][CH];
+    uint32_t cur_i;
+#define QR_ROW_I(U) row_bcast_u32<(U)>(my_i)
+#define QR_ROW_J(U) row_bcast_u32<(U)>(my_j)
+    cur_i = QR_ROW_I(0);
+    load_row(a, row_of(cur_i));
+    // prologue: the second rows of pairs 0 .. PF - 1
+#define QR_PRO(U) \
+    if ((U) < SCORE_PF) load_row(cb[(U) % NB], row_of(QR_ROW_J(U)));
+    QR_PRO(0) QR_PRO(1) QR_PRO(2) QR_PRO(3)
+#undef QR_PRO
+    static_assert(SCORE_PF >= 1 && SCORE_PF <= 4, "prefetch depth");
+#define QR_STEP(U)                                                                          \
+    {                                                                                       \
+      if ((U) + SCORE_PF < SCORE_LPP) load_row(cb[((U) + SCORE_PF) % NB], row_of(QR_ROW_J(((U) + SCORE_PF) % SCORE_LPP))); \
+      uint64_t part = 0;                                                                    \
+      _Pragma("unroll") for (int k = 0; k < CH; ++k) part += chunk_dot(a[k], cb[(U) % NB][k]); \
+      const uint64_t tot = row_sum_u64(part);                                               \
+      if (lig == (U)) my_dot = tot;                                                         \
+      if ((U) + 1 < SCORE_LPP) {                                                            \
+        const uint32_t ni = QR_ROW_I(((U) + 1) % SCORE_LPP);                                \
+        if (ni != cur_i) load_row(a, row_of(ni));                                           \
+        cur_i = ni;                                                                         \
+      }                                                                                     \
+    }
+    QR_STEP(0) QR_STEP(1) QR_STEP(2) QR_STEP(3) QR_STEP(4) QR_STEP(5) QR_STEP(6) QR_STEP(7)
+    QR_STEP(8) QR_STEP(9) QR_STEP(10) QR_STEP(11) QR_STEP(12) QR_STEP(13) QR_STEP(14) QR_STEP(15)
+#undef QR_STEP
+#undef QR_ROW_I
+#undef QR_ROW_J
+    if (live) {
+      const int64_t dot = (int64_t)my_dot;
+      double cs = 0.0;
+      if (na != 0 && nb != 0) cs = (double)dot / (sqrt((double)na) * sqrt((double)nb));
+      const int32_t mi = (int32_t)rint(cs * 1000.0);
+      milli[t] = mi;
+      if (cosv) cosv[t] = cs;
+      if (edges) {
+        const uint64_t inv = (uint64_t)(1000 - mi), i = my_i, j = my_j;
+        if (rev_only) {
+          if (edge_dst) {
+            edges[t] = (j << 11) | inv;
+            edge_dst[t] = (uint32_t)i;
+          } else {
+            edges[t] = (j << (id_bits + 11)) | (inv << id_bits) | i;
+          }
+        } else if (edge_dst) {
+          edges[2 * t] = (i << 11) | inv;
+          edges[2 * t + 1] = (j << 11) | inv;
+          edge_dst[2 * t] = (uint32_t)j;
+          edge_dst[2 * t + 1] = (uint32_t)i;
+        } else {
+          edges[2 * t] = (i << (id_bits + 11)) | (inv << id_bits) | j;
+          edges[2 * t + 1] = (j << (id_bits + 11)) | (inv << id_bits) | i;
+        }
+      }
+    }
+  }
+}
+
+static int g_score_runs = -1;   // -1: read QRLSH_SCORE_RUNS on first use (default on)
+// 1: compact 128 / 256-value rows are scored by the run form (default), 0: by the generic form (same results; an A/B
+// and test knob).  Returns the previous setting.
+QRLSH_EXPORT int qrlsh_set_score_runs(int on) {
+  const int old = g_score_runs;
+  g_score_runs = on != 0;
+  return old;
+}
+
 static int score_launch(const void *sig, const void *sig_b, int64_t split, int32_t sig_dtype, const int64_t *norm2,
                         const int64_t *norm2_b, int32_t P, const uint64_t *pairs, int64_t n, int32_t *milli_out,
                         double *cos_out, uint64_t *edge_out, int32_t id_bits, uint32_t *edge_dst_out, void *stream,
@@ -180,6 +345,24 @@ static int score_launch(const void *sig, const void *sig_b, int64_t split, int32
   const uint32_t sp = split >= (1ll << 32) ? 0xFFFFFFFFu : (uint32_t)split;
   if (sig_dtype == QRLSH_SIG_U16) {
     const uint16_t *s16 = static_cast<const uint16_t *>(sig), *s16b = static_cast<const uint16_t *>(sig_b);
+    // the run form: compact rows of 128 / 256 values, precomputed norms (QRLSH_SCORE_RUNS=0: the generic form)
+    if (g_score_runs < 0) {
+      const char *e = getenv("QRLSH_SCORE_RUNS");
+      g_score_runs = !(e && e[0] == '0');
+    }
+    if (g_score_runs && aligned && norm2 && (P == 128 || P == 256) && (sig_b == nullptr || norm2_b)) {
+      int64_t rb = ceil_div64(ceil_div64(n, SCORE_LPP), groups_per_block);
+      if (rb > 256 * 8) rb = 256 * 8;   // eight workgroups per CU, each group walking its chunks
+      const dim3 rgrid((unsigned)rb);
+      if (P == 128)
+        QR_LAUNCH("score_pairs", (score_runs_kernel<1>), rgrid, block, 0, st, s16, norm2, pairs, n, milli_out, cos_out,
+                  edge_out, id_bits, edge_dst_out, s16b, norm2_b, sp, rev_only);
+      else
+        QR_LAUNCH("score_pairs", (score_runs_kernel<2>), rgrid, block, 0, st, s16, norm2, pairs, n, milli_out, cos_out,
+                  edge_out, id_bits, edge_dst_out, s16b, norm2_b, sp, rev_only);
+      QR_LAUNCH_CHECK("qrlsh_score_pairs");
+      return QRLSH_OK;
+    }
     if (aligned && P % 8 == 0)
       QR_LAUNCH("score_pairs", (score_pairs_kernel<uint16_t, true>), grid, block, 0, st, s16, norm2, P, pairs, n, milli_out,
                 cos_out, edge_out, id_bits, edge_dst_out, s16b, norm2_b, sp, rev_only);

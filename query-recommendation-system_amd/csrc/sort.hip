@@ -525,6 +525,27 @@ __global__ __launch_bounds__(SORT_THREADS, 3) void part_scatter_staged_kernel(
 // LEVEL2 = true : finer partitions (T > 8 bits) take a second step -- the input is the OUTPUT of a first
 // step, one batch per (band, coarse part): its in_counts[batch] records sit at batch * in_cap and are
 // dealt to nd = 2^(T-c1) fine parts by the next bits of the same hash; ids come with the records.
+// OVERFLOW POOL (round 4).  A part's region holds ONE LDS image of the finish (reserved memory ~ 1.7 - 2 x the records
+// instead of the 7.6 x of three-image regions), and a part swollen by a popular key -- at 100 M queries over 32768
+// table rows the luckiest (row, band) makes one band key common to ~20 000 queries -- spills into a pool shared by all
+// parts: a (tile, part) run that does not fit the part's region takes its room from a device bump cursor instead and
+// leaves a descriptor {part slot, records, pool position}; the first such run also records how many records the
+// region really holds (`fill`: reservations are handed out in cursor order, so the region holds a prefix of them).
+// The finish lists such parts like every part beyond its image; bucket_big_gather_kernel then puts each one's records
+// (region prefix + its runs) next to each other in the pool, where the block kernel works them.  No pool (keys ==
+// nullptr: the coarse step of a two-step partition): an overflowing part raises the flag, as before.
+struct PartPool {
+  uint64_t *keys;               // pool records (the x words) ...
+  uint32_t *vals;               // ... and their ids
+  unsigned long long *cursor;   // records handed out so far
+  uint32_t cap;                 // records the pool holds (< 2^32)
+  uint4 *runs;                  // {part slot, records, pool position, 0} per spilled run
+  unsigned long long *nruns;
+  uint32_t runs_max;
+  uint32_t *fill;               // per part slot: records that sit in its region (0xFFFFFFFF: all of them)
+  uint32_t slot_base;           // part slot of this launch's (batch 0, part 0)
+};
+
 constexpr int PS_IPT = 16;  // records per thread of the atomic partition (8, six workgroups per CU: 3.9 ms against 3.4)
 constexpr int PS_TILE = SORT_THREADS * PS_IPT;
 constexpr int PS_WGS = 3;   // workgroups per CU the 50 KB LDS image allows
@@ -534,7 +555,7 @@ __global__ __launch_bounds__(SORT_THREADS, PS_WGS) void part_scatter_atomic_kern
     uint32_t *__restrict__ vals_out, int64_t n_in, int ntiles, int shift, uint32_t dmask,
     uint32_t *__restrict__ cursors, uint32_t cap, uint32_t *__restrict__ overflow, uint64_t ek,
     const uint32_t *__restrict__ in_counts, uint32_t in_cap, int64_t chunk_len, int64_t chunk_stride,
-    int64_t band_stride) {
+    int64_t band_stride, PartPool pool) {
   // What travels through the partition is x = mix64(key), not the key: mix64 is a bijection, so equal x <=> equal
   // keys and the finish can pair on x; the part number of either step is then a shift of the staged word (no
   // second hash in the second step, none at the write-out, nothing to carry in the id word -- ids keep all 32
@@ -613,10 +634,27 @@ __global__ __launch_bounds__(SORT_THREADS, PS_WGS) void part_scatter_atomic_kern
   }
   {
     const int d = threadIdx.x;
-    const bool ok = gb + tc <= cap;
-    if (!ok) atomicOr(overflow, 1u);
-    gok[d] = ok;
-    gdelta[d] = (uint32_t)d * cap + gb - lstart;  // mod 2^32; + the staged position gives the place in the batch
+    uint32_t where = gb + tc <= cap ? 1u : 0u;    // 1: the part's region, 2: the pool, 0: nowhere (overflow flag)
+    uint32_t delta = (uint32_t)d * cap + gb - lstart;  // mod 2^32; + the staged position gives the place in the batch
+    if (!where) {
+      if (pool.keys) {  // the run spills: room from the pool's cursor, a descriptor, the region's fill mark
+        const unsigned long long pb =
+            __hip_atomic_fetch_add(pool.cursor, (unsigned long long)tc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (pb + tc <= (unsigned long long)pool.cap) {
+          const unsigned long long ri = __hip_atomic_fetch_add(pool.nruns, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (ri < (unsigned long long)pool.runs_max) {
+            const uint32_t slot = pool.slot_base + (uint32_t)batch * nd + (uint32_t)d;
+            pool.runs[ri] = make_uint4(slot, tc, (uint32_t)pb, 0u);
+            atomicMin(&pool.fill[slot], gb);
+            where = 2u;
+            delta = (uint32_t)pb - lstart;
+          }
+        }
+      }
+      if (!where) atomicOr(overflow, 1u);
+    }
+    gok[d] = (uint8_t)where;
+    gdelta[d] = delta;
   }
   __syncthreads();
   uint32_t nstaged = 0;  // records of the tile that are not of an empty band
@@ -629,10 +667,15 @@ __global__ __launch_bounds__(SORT_THREADS, PS_WGS) void part_scatter_atomic_kern
     if (p < nstaged) {
       const uint64_t x = skey[p];
       const uint32_t d = (uint32_t)(x >> shift) & dmask;
-      if (gok[d]) {
+      const uint32_t where = gok[d];
+      if (where == 1u) {
         const size_t dst = obase + (uint32_t)(gdelta[d] + p);
         keys_out[dst] = x;
         vals_out[dst] = sval[p];
+      } else if (where == 2u) {
+        const uint32_t dst = gdelta[d] + p;
+        pool.keys[dst] = x;
+        pool.vals[dst] = sval[p];
       }
     }
   }
@@ -886,10 +929,10 @@ __global__ __launch_bounds__(THREADS, THREADS >= 1024 ? 8 : 6) void bucket_finis
   const size_t first = counts ? bslot * cap : (size_t)band * nq + start;
   if (m > (uint32_t)CAP || (counts && m > cap)) {  // uniform over the workgroup
     if (tid == 0) {
-      // a part that holds more records than the LDS image (a popular key with thousands of copies, mostly) but
-      // fits its region: left to bucket_finish_big_kernel, which works it in blocks -- one-pass form only
+      // a part that holds more records than the LDS image (a popular key with thousands of copies, mostly), in its
+      // region or spilled into the pool: left to bucket_finish_big_kernel, which works it in blocks -- one-pass form only
       bool listed = false;
-      if (MODE == FIN_EMIT && biglist && counts && m <= cap) {
+      if (MODE == FIN_EMIT && biglist && counts) {
         const unsigned long long at =
             __hip_atomic_fetch_add(nbig, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (at < (unsigned long long)big_max) {
@@ -1031,23 +1074,103 @@ __global__ __launch_bounds__(THREADS, THREADS >= 1024 ? 8 : 6) void bucket_finis
   }
 }
 
-// Parts the kernel above listed (more records than its LDS image, all inside their region): worked in BLOCKS of
+// Parts the kernel above listed (more records than its LDS image): worked in BLOCKS of
 // FIN_CAP records by workgroups that walk the device-side list (fixed grid; nothing is read back to size the
 // launch).  Block bi is finished exactly like a small part (hash table on the full word, arrival numbers, bucket
 // runs laid out in LDS -> its own pairs); then every EARLIER block's records are streamed past bi's table: a
 // record whose word is in the table pairs with every id of that bucket's run.  Together: every pair of equal words
-// of the part, once -- a key with any number of copies up to the region's size is no special case any more.
+// of the part, once -- a key with any number of copies up to FIN_BIG_BLOCKS images is no special case any more.
 // Output ranges are reserved on the same device cursor as the small parts'.
 constexpr int FIN_BIG_GRID = 256;
-#ifndef QR_FIN_BIG_FACTOR
-#define QR_FIN_BIG_FACTOR 3
-#endif
-constexpr int FIN_BIG_FACTOR = QR_FIN_BIG_FACTOR;  // a part's region holds this many LDS images
-constexpr uint32_t FIN_BIG_LIST = 65536;  // listed parts per call; beyond: overflow flag (general path)
+constexpr int FIN_BIG_BLOCKS = 16;        // blocks of FIN_CAP records a listed part may hold (98 304); beyond: overflow flag
+constexpr uint32_t FIN_BIG_LIST = 4096;   // listed parts per band group and call; beyond: overflow flag (general path)
 constexpr int FIN_BIG_SLICES = 8;         // workgroups that share a block pair's pairs (a power of two)
+constexpr uint32_t POOL_RUNS = 1u << 20;  // spilled-run descriptors per call; beyond: overflow flag
+
+// where the records of a listed part sit: `pool` = 0: in the part buffers at `where` (its own region), 1: in the
+// pool at `where` (gathered there by the kernel below); m = 0: nothing to do (the overflow flag is up)
+struct BigDesc {
+  uint64_t where;
+  uint32_t m, pool;
+};
+
+// One workgroup per listed part: a part that spilled (fill mark set) gets m records of room at the pool's cursor and
+// its records -- the prefix its region holds and every run of the descriptor list that names it -- are copied there,
+// next to each other in any order (the finish does not care); a part that fits its region is described in place.
+__global__ __launch_bounds__(256) void bucket_big_gather_kernel(const uint64_t *__restrict__ biglist,
+                                                                const unsigned long long *__restrict__ nbig, uint32_t big_max,
+                                                                BigDesc *__restrict__ desc, const uint64_t *__restrict__ part_keys,
+                                                                const uint32_t *__restrict__ part_ids,
+                                                                const uint32_t *__restrict__ counts, uint32_t cap, PartPool pool,
+                                                                uint32_t max_records, uint32_t *__restrict__ overflow) {
+  __shared__ unsigned long long base_s;
+  __shared__ uint32_t match[256];
+  __shared__ uint32_t nmatch;
+  const int tid = threadIdx.x;
+  unsigned long long nb = *nbig;
+  if (nb > big_max) nb = big_max;
+  for (unsigned long long e = blockIdx.x; e < nb; e += gridDim.x) {
+    const uint32_t slot = (uint32_t)biglist[e];
+    const uint32_t m = counts[slot];
+    const uint32_t f = pool.fill ? pool.fill[slot] : 0xFFFFFFFFu;
+    if (m > max_records || (f == 0xFFFFFFFFu && m > cap)) {  // (uniform) too large / records were dropped
+      if (tid == 0) {
+        atomicOr(overflow, 1u);
+        desc[e] = BigDesc{0ull, 0u, 0u};
+      }
+      continue;
+    }
+    if (f == 0xFFFFFFFFu) {  // all in its region
+      if (tid == 0) desc[e] = BigDesc{(uint64_t)slot * cap, m, 0u};
+      continue;
+    }
+    __syncthreads();  // (the previous part's base_s has been read by everyone)
+    if (tid == 0)
+      base_s = __hip_atomic_fetch_add(pool.cursor, (unsigned long long)m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned long long base = base_s;
+    if (base + m > (unsigned long long)pool.cap) {  // uniform
+      if (tid == 0) {
+        atomicOr(overflow, 1u);
+        desc[e] = BigDesc{0ull, 0u, 0u};
+      }
+      continue;
+    }
+    for (uint32_t i = tid; i < f; i += blockDim.x) {
+      pool.keys[base + i] = part_keys[(size_t)slot * cap + i];
+      pool.vals[base + i] = part_ids[(size_t)slot * cap + i];
+    }
+    uint32_t at = f;
+    unsigned long long nr = *pool.nruns;
+    if (nr > pool.runs_max) nr = pool.runs_max;
+    for (unsigned long long r0 = 0; r0 < nr; r0 += blockDim.x) {
+      __syncthreads();
+      if (tid == 0) nmatch = 0;
+      __syncthreads();
+      const unsigned long long r = r0 + tid;
+      if (r < nr && pool.runs[r].x == slot) match[atomicAdd(&nmatch, 1u)] = (uint32_t)r;
+      __syncthreads();
+      const uint32_t nm = nmatch;
+      for (uint32_t q = 0; q < nm; ++q) {
+        const uint4 run = pool.runs[match[q]];
+        if (at + run.y <= m)
+          for (uint32_t i = tid; i < run.y; i += blockDim.x) {
+            pool.keys[base + at + i] = pool.keys[(size_t)run.z + i];
+            pool.vals[base + at + i] = pool.vals[(size_t)run.z + i];
+          }
+        at += run.y;
+      }
+    }
+    if (tid == 0) {
+      if (at != m) atomicOr(overflow, 1u);  // (cannot happen: every record of the part is in its region or in a run)
+      desc[e] = BigDesc{(uint64_t)base, at == m ? m : 0u, 1u};
+    }
+  }
+}
+
 __global__ __launch_bounds__(FIN_THREADS) void bucket_finish_big_kernel(
-    const uint64_t *__restrict__ keys, const uint32_t *__restrict__ ids, const uint32_t *__restrict__ counts, uint32_t cap,
-    uint64_t ek, const uint64_t *__restrict__ biglist, const unsigned long long *__restrict__ nbig, uint32_t big_max,
+    const uint64_t *__restrict__ keys, const uint32_t *__restrict__ ids, const uint64_t *pool_keys, const uint32_t *pool_ids,
+    uint64_t ek, const BigDesc *__restrict__ desc, const unsigned long long *__restrict__ nbig, uint32_t big_max,
     uint64_t *__restrict__ blk, uint64_t *__restrict__ out, uint64_t capacity) {
   __shared__ unsigned long long gbase;
   __shared__ __attribute__((aligned(16))) unsigned long long tab[FIN_CAP];
@@ -1086,22 +1209,22 @@ __global__ __launch_bounds__(FIN_THREADS) void bucket_finish_big_kernel(
   // from build to build, so a slice is defined on something the builds share: bi's own pairs go by the RANK of a
   // record's query id among its bucket-mates (the runs are sorted by id; a record pairs with the mates of smaller
   // id, and belongs to slice rank mod 8), bj's records by their position in bj (mod 8).
-  constexpr int COMBOS = FIN_BIG_FACTOR * (FIN_BIG_FACTOR + 1) / 2;
+  constexpr int COMBOS = FIN_BIG_BLOCKS * (FIN_BIG_BLOCKS + 1) / 2;
   static_assert(FIN_THREADS % FIN_BIG_SLICES == 0, "a thread's records share their position mod the slice count");
   for (unsigned long long item = blockIdx.x; item < nb * COMBOS * FIN_BIG_SLICES; item += gridDim.x) {
     const uint32_t sl = (uint32_t)(item % FIN_BIG_SLICES);
     const unsigned long long e = item / ((unsigned long long)COMBOS * FIN_BIG_SLICES);
     int combo = (int)((item / FIN_BIG_SLICES) % COMBOS);
     uint32_t bi = 0;
-    while (combo > (int)bi) {  // combos in the order (0,0) (1,0) (1,1) (2,0) (2,1) (2,2)
+    while (combo > (int)bi) {  // combos in the order (0,0) (1,0) (1,1) (2,0) (2,1) (2,2) ...
       combo -= (int)bi + 1;
       ++bi;
     }
     const uint32_t bj_only = (uint32_t)combo;
-    const size_t bslot = (size_t)biglist[e];
-    const uint32_t m = min(counts[bslot], cap);
-    const uint64_t *k = keys + bslot * cap;
-    const uint32_t *id = ids + bslot * cap;
+    const BigDesc de = desc[e];
+    const uint32_t m = de.m;
+    const uint64_t *k = (de.pool ? pool_keys : keys) + de.where;
+    const uint32_t *id = (de.pool ? pool_ids : ids) + de.where;
     const uint32_t nblk = (m + FIN_CAP - 1) / FIN_CAP;
     if (bi >= nblk) continue;  // uniform
     {
@@ -1247,12 +1370,26 @@ __global__ __launch_bounds__(FIN_THREADS) void bucket_finish_big_kernel(
   }
 }
 
+// records a listed part may hold (qrlsh_set_big_part_limit; default and maximum: FIN_BIG_BLOCKS images)
+static uint32_t g_big_limit = (uint32_t)FIN_BIG_BLOCKS * FIN_CAP;
+QRLSH_EXPORT int64_t qrlsh_set_big_part_limit(int64_t records) {
+  const int64_t max = (int64_t)FIN_BIG_BLOCKS * FIN_CAP, old = g_big_limit;
+  g_big_limit = (uint32_t)(records <= 0 || records > max ? max : records);
+  return old;
+}
+
 // workspace: [ghist + rtot of one sort pass][starts: b*(2^T+1) u32][blk: b*2^T u64][16 B tail]
+//            [fill: b*2^T u32][pool cursor, run count: 2 u64][runs: POOL_RUNS x 16 B][desc: 16 x FIN_BIG_LIST x 16 B]
 static size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+constexpr int EMIT_MAX_GROUPS = 16;  // band groups of one qrlsh_bucket_pairs_emit call
 struct BucketWs {
   uint32_t *ghist, *rtot, *starts;
   uint64_t *blk;
   uint32_t *tail;
+  uint32_t *fill;
+  unsigned long long *poolctl;
+  uint4 *runs;
+  BigDesc *desc;
   size_t bytes;
 };
 static BucketWs bucket_ws(void *workspace, int64_t nq, int32_t b, int32_t T) {
@@ -1270,6 +1407,14 @@ static BucketWs bucket_ws(void *workspace, int64_t nq, int32_t b, int32_t T) {
   off += (size_t)b * nparts * sizeof(uint64_t);
   w.tail = reinterpret_cast<uint32_t *>(p + off);
   off += 16;
+  w.fill = reinterpret_cast<uint32_t *>(p + off);
+  off += align16((size_t)b * nparts * sizeof(uint32_t));
+  w.poolctl = reinterpret_cast<unsigned long long *>(p + off);
+  off += 16;
+  w.runs = reinterpret_cast<uint4 *>(p + off);
+  off += (size_t)POOL_RUNS * sizeof(uint4);
+  w.desc = reinterpret_cast<BigDesc *>(p + off);
+  off += (size_t)EMIT_MAX_GROUPS * FIN_BIG_LIST * sizeof(BigDesc);
   w.bytes = off;
   return w;
 }
@@ -1373,9 +1518,9 @@ QRLSH_EXPORT int qrlsh_bucket_pairs_count(const uint64_t *keys, uint64_t *part_k
 // finish for full-size inputs, mean + 50 % + 512 for small ones
 static uint32_t part_region(int64_t nq) {
   const int64_t c = ((nq / RADIX) * 3 / 2 + 512 + 63) / 64 * 64;
-  // full-size inputs: room for FIN_BIG_FACTOR images, so that a part swollen by a popular key stays inside its
-  // region and goes to bucket_finish_big_kernel instead of sending the whole step to the general path
-  return (uint32_t)(c < FIN_CAP ? c : FIN_BIG_FACTOR * FIN_CAP);
+  // full-size inputs: ONE image of the finish; a part swollen by a popular key spills into the overflow pool and goes
+  // to bucket_finish_big_kernel instead of sending the whole step to the general path
+  return (uint32_t)(c < FIN_CAP ? c : FIN_CAP);
 }
 
 // finer partitions (T > 8) go through two such kernels: 2^c1 coarse regions per band, then 2^(T-c1) fine
@@ -1390,22 +1535,35 @@ static uint32_t coarse_region(int64_t nq, int c1) {
   const double slack = a >= 4096.0 ? 0.25 * a + 8192.0 : 6.0 * sqrt(a) + 2.0 * a + 64.0;
   return (uint32_t)(((int64_t)(a + slack) + 63) / 64 * 64);
 }
+// small parts: the 512-thread / 4096-slot form of the finish (three workgroups per CU)
+static bool small_form(int64_t nq, int T) { return (nq >> T) >= 1024 && (nq >> T) <= FIN_SMALL_MEAN; }
 static uint32_t fine_region(int64_t nq, int T) {
-  // real sizes (mean >= 1024 records per part): the whole LDS image, so that a popular key with a few
-  // thousand copies still fits its part, as in the sort-based partition; tiny inputs: 2 x mean + 128
-  if ((nq >> T) >= 1024) return FIN_BIG_FACTOR * FIN_CAP;
+  // real sizes (mean >= 1024 records per part): the LDS image of the finish form that will run (4096 records for
+  // means up to 2800 -- 10 M queries: 2441 --, else 6144): reserved = 1.4 - 2 x the records; a part swollen by a
+  // popular key spills into the pool.  Tiny inputs: 2 x mean + 128
+  if ((nq >> T) >= 1024) return small_form(nq, T) ? FIN_SMALL_CAP : FIN_CAP;
   const int64_t c = ((nq >> T) * 2 + 128 + 63) / 64 * 64;
   return (uint32_t)(c < FIN_CAP ? c : FIN_CAP);
 }
 static bool one_kernel_partition(int64_t nq, int part_bits) { return nq < (1ll << 32) && part_bits >= 8; }
+// records of the overflow pool behind the regions: 1/16 of the records of the call (what popular keys spill, plus the
+// gathered copies of the spilled parts), at least 1 M, below 2^32
+static size_t pool_records(int64_t nq, int32_t b) {
+  size_t n = (size_t)b * (size_t)nq / 16;
+  if (n < ((size_t)1 << 20)) n = (size_t)1 << 20;
+  if (n > 0xFFFFFF00ull) n = 0xFFFFFF00ull;
+  return n;
+}
+static size_t region_words(int64_t nq, int32_t b, int32_t part_bits) {
+  return part_bits == 8 ? (size_t)b * RADIX * part_region(nq) : ((size_t)b << part_bits) * fine_region(nq, part_bits);
+}
 
 // words part_keys / part_ids (and, for part_bits > 8, tmp_keys / tmp_ids) must hold for qrlsh_bucket_pairs_emit
 QRLSH_EXPORT size_t qrlsh_bucket_part_words(int64_t nq, int32_t b, int32_t part_bits) {
   if (nq <= 0 || b <= 0) return 0;
   const size_t plain = (size_t)b * nq;
   if (!one_kernel_partition(nq, part_bits)) return plain;
-  const size_t regions = part_bits == 8 ? (size_t)b * RADIX * part_region(nq)
-                                        : ((size_t)b << part_bits) * fine_region(nq, part_bits);
+  const size_t regions = region_words(nq, b, part_bits) + pool_records(nq, b);   // [regions][overflow pool]
   return regions > plain ? regions : plain;
 }
 QRLSH_EXPORT size_t qrlsh_bucket_tmp_words(int64_t nq, int32_t b, int32_t part_bits) {
@@ -1473,9 +1631,30 @@ QRLSH_EXPORT int qrlsh_bucket_pairs_emit_chunked(const uint64_t *keys, int64_t k
       return QRLSH_EHIP;
     }
     uint32_t *ovf = reinterpret_cast<uint32_t *>(total_overflow_out + 1);
+    // the overflow pool behind the regions of the part buffers (PartPool above); the step that fills the parts the
+    // finish reads spills into it (the coarse step of a two-step partition does not: its regions have their own slack)
+    const size_t reg_words = region_words(nq, b, T);
+    PartPool pool;
+    pool.keys = part_keys + reg_words;
+    pool.vals = part_ids + reg_words;
+    pool.cursor = w.poolctl;
+    pool.nruns = w.poolctl + 1;
+    pool.cap = (uint32_t)pool_records(nq, b);
+    pool.runs = w.runs;
+    pool.runs_max = POOL_RUNS;
+    pool.fill = w.fill;
+    pool.slot_base = 0;
+    PartPool no_pool = pool;
+    no_pool.keys = nullptr;
+    no_pool.vals = nullptr;
+    if (hipMemsetAsync(w.fill, 0xFF, ((size_t)b << T) * sizeof(uint32_t), st) != hipSuccess ||
+        hipMemsetAsync(w.poolctl, 0, 16, st) != hipSuccess) {
+      qrlsh_set_error("qrlsh_bucket_pairs_emit: hipMemsetAsync failed");
+      return QRLSH_EHIP;
+    }
     // lists of the parts that outgrow the LDS image (bucket_finish_big_kernel), one per band group, in the count /
     // fill form's block area: [16 counters][group 0's list][group 1's list] ...
-    constexpr int MAX_GROUPS = 16;
+    constexpr int MAX_GROUPS = EMIT_MAX_GROUPS;
     unsigned long long *nbig0 = reinterpret_cast<unsigned long long *>(w.blk);
     uint64_t *biglist0 = w.blk + MAX_GROUPS;
     const uint64_t slots = (uint64_t)b << T;  // >= 256 words in the block area
@@ -1483,8 +1662,8 @@ QRLSH_EXPORT int qrlsh_bucket_pairs_emit_chunked(const uint64_t *keys, int64_t k
       qrlsh_set_error("qrlsh_bucket_pairs_emit: hipMemsetAsync failed");
       return QRLSH_EHIP;
     }
-    // small parts (and regions that can hold what the small image cannot): the 512-thread / 4096-slot finish
-    const bool small_parts = (nq >> T) <= FIN_SMALL_MEAN && cap2 > (uint32_t)FIN_SMALL_CAP;
+    // small parts: the 512-thread / 4096-slot finish
+    const bool small_parts = two && small_form(nq, T);
     const int ntiles = (int)ceil_div64(nq, PS_TILE);
     const int64_t band_words = key_band_stride ? key_band_stride : nq;  // words between two bands of the key matrix
     static int groups_env = -1;
@@ -1510,17 +1689,19 @@ QRLSH_EXPORT int qrlsh_bucket_pairs_emit_chunked(const uint64_t *keys, int64_t k
       unsigned long long *nbig = nbig0 + gi;
       uint64_t *k1 = two ? tmp_keys : part_keys;
       uint32_t *v1 = two ? tmp_ids : part_ids;
+      pool.slot_base = (uint32_t)((size_t)g0 << T);
+      BigDesc *desc = w.desc + (size_t)gi * FIN_BIG_LIST;
       QR_PART_SCATTER(false, dim3(ntiles, nb), dim3(SORT_THREADS), 0, s, keys + (size_t)g0 * band_words,
                       (const uint32_t *)nullptr, k1 + ((size_t)g0 << c1) * cap1, v1 + ((size_t)g0 << c1) * cap1, nq,
                       ntiles, 64 - c1, (1u << c1) - 1u, cur1 + ((size_t)g0 << c1), cap1, ovf, qr_empty_key(r),
-                      (const uint32_t *)nullptr, 0u, key_chunk, key_chunk_stride, key_band_stride);
+                      (const uint32_t *)nullptr, 0u, key_chunk, key_chunk_stride, key_band_stride, two ? no_pool : pool);
       if (two)
         QR_PART_SCATTER(true, dim3((unsigned)ceil_div64(cap1, PS_TILE), nb << c1), dim3(SORT_THREADS), 0, s,
                         (const uint64_t *)tmp_keys + ((size_t)g0 << c1) * cap1,
                         (const uint32_t *)tmp_ids + ((size_t)g0 << c1) * cap1, part_keys + ((size_t)g0 << T) * cap2,
                         part_ids + ((size_t)g0 << T) * cap2, (int64_t)0, 0, 64 - T, lowmask, cur2 + ((size_t)g0 << T),
                         cap2, ovf, qr_empty_key(r), (const uint32_t *)cur1 + ((size_t)g0 << c1), cap1, (int64_t)0,
-                        (int64_t)0, (int64_t)0);
+                        (int64_t)0, (int64_t)0, pool);
       // the auxiliary stream is forked once the first group's partition is queued and before its finish is: the
       // second group's partition then starts beside the first group's finish, and the two streams stay half a
       // group out of step
@@ -1538,11 +1719,15 @@ QRLSH_EXPORT int qrlsh_bucket_pairs_emit_chunked(const uint64_t *keys, int64_t k
                   (const uint32_t *)cur2 + ((size_t)g0 << T), cap2, biglist, nbig, big_max, (uint32_t)((size_t)g0 << T));
       // the parts of this group the finish listed as larger than its LDS image (usually none: the kernel then finds
       // an empty list), on the group's own stream: they are worked beside the next group
+      QR_LAUNCH("bucket_emit_big", bucket_big_gather_kernel, dim3(64), dim3(256), 0, s, (const uint64_t *)biglist,
+                (const unsigned long long *)nbig, big_max, desc, (const uint64_t *)part_keys, (const uint32_t *)part_ids,
+                (const uint32_t *)cur2, cap2, pool, g_big_limit, ovf);
       QR_LAUNCH("bucket_emit_big", bucket_finish_big_kernel, dim3(FIN_BIG_GRID), dim3(FIN_THREADS), 0, s,
-                (const uint64_t *)part_keys, (const uint32_t *)part_ids, (const uint32_t *)cur2, cap2, ekx,
-                (const uint64_t *)biglist, (const unsigned long long *)nbig, big_max, total_overflow_out, pairs_out, capacity);
+                (const uint64_t *)part_keys, (const uint32_t *)part_ids, (const uint64_t *)pool.keys,
+                (const uint32_t *)pool.vals, ekx, (const BigDesc *)desc, (const unsigned long long *)nbig, big_max,
+                total_overflow_out, pairs_out, capacity);
     }
-    if (aux) qr_aux_join(st);
+    if (aux && qr_aux_join(st) != QRLSH_OK) return QRLSH_EHIP;
     QR_LAUNCH_CHECK("qrlsh_bucket_pairs_emit");
     return QRLSH_OK;
   }

@@ -53,7 +53,7 @@ class LSH:
     def get_candidates(self, signatures=None):
         """set of (i, j), i < j, sharing at least one non-empty band (lsh.py:40-55).
         `signatures` is accepted and ignored, as in the reference."""
-        pairs = self.get_candidates_array().cpu().numpy()
+        pairs = ops.to_host(self.get_candidates_array())
         i = (pairs >> 32).astype(np.int64)
         j = (pairs & 0xFFFFFFFF).astype(np.int64)
         return set(zip(i.tolist(), j.tolist()))
@@ -115,7 +115,7 @@ class LSH:
     def _materialise_buckets(self):
         """The reference's `buckets` attribute (list of b dicts "v0,v1,.." -> [ids]), rebuilt on
         request from the registered signatures; insertion order = first appearance by id."""
-        sig = ops.sig_to_int32(self.signatures_tensor()).cpu().numpy()
+        sig = ops.to_host(ops.sig_to_int32(self.signatures_tensor()))
         out = [dict() for _ in range(self.b)]
         n, P = sig.shape
         if n == 0:

@@ -53,6 +53,8 @@ SIGNATURES = {
     "qrlsh_bucket_pairs_fill": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "qrlsh_bucket_pairs_emit_chunked": (ctypes.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp, _u64, _vp, _vp]),
     "qrlsh_bucket_part_words": (_sz, [_i64, _i32, _i32]),
+    "qrlsh_set_big_part_limit": (_i64, [_i64]),
+    "qrlsh_set_score_runs": (_i32, [_i32]),
     "qrlsh_bucket_tmp_words": (_sz, [_i64, _i32, _i32]),
     "qrlsh_bucket_pairs_emit": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp, _u64, _vp, _vp]),
     "qrlsh_compact_workspace_bytes": (_sz, [_i64]),

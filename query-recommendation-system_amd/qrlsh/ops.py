@@ -40,6 +40,21 @@ def _ws(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
 
+def to_host(t):
+    """device tensor -> numpy array through PINNED host memory (torch's caching host allocator: the first copy of a
+    size pays for the pinning, later ones reuse the block once the array it backed is gone).  A plain `.cpu()` lands
+    in pageable memory at ~6 GB/s -- 139 ms for the 786 MB of top-K rows of a 10 M-query step, 7 x the step itself;
+    the pinned copy runs at the link's rate.  The array owns its buffer (nothing is shared between calls)."""
+    if not isinstance(t, torch.Tensor):
+        return np.asarray(t)
+    if not t.is_cuda:
+        return t.numpy()
+    h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    h.copy_(t, non_blocking=True)
+    torch.cuda.current_stream(t.device).synchronize()
+    return h.numpy()
+
+
 def id_bits_for(nq):
     """bits needed for a query id in [0, nq)"""
     return max(1, int(nq - 1).bit_length()) if nq > 1 else 1

@@ -103,9 +103,7 @@ def sims_to_dict(src, dst, val):
     """COO top-K -> the dict recommender.py:206-214 returns:
     {q: {'indexes': int64[<=K], 'values': float64[<=K] descending}}; queries without
     candidates are absent (the consumer tests `j in querySimilarities`, :314)."""
-    src = src.cpu().numpy() if isinstance(src, torch.Tensor) else np.asarray(src)
-    dst = dst.cpu().numpy() if isinstance(dst, torch.Tensor) else np.asarray(dst)
-    val = val.cpu().numpy() if isinstance(val, torch.Tensor) else np.asarray(val)
+    src, dst, val = ops.to_host(src), ops.to_host(dst), ops.to_host(val)   # (pinned staging: the link's rate)
     out = {}
     if len(src) == 0:
         return out

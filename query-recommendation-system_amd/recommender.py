@@ -115,7 +115,7 @@ class Recommender:
     def answer_sets(self):
         """host copy of answer_sets_device(): (offsets int64 [nq+1], rows int32 [nnz])"""
         off, rows = self.answer_sets_device()
-        off, rows = off.cpu().numpy(), rows.cpu().numpy()
+        off, rows = ops.to_host(off), ops.to_host(rows)
         for q, n in enumerate(np.diff(off)):
             self.tupleCount[q] = int(n)      # recommender.py:93
         return off, rows
@@ -148,7 +148,7 @@ class Recommender:
         initial = time.time()
         offsets, rows, table = self._device_inputs()
         sig, _, _ = ops.minhash(offsets, rows, table, b=None, want_norm=False)
-        out = sig.cpu().numpy().astype(np.int64)
+        out = ops.to_host(sig).astype(np.int64)
         self._log(str(round(time.time() - initial, 3)) + "s for signature_matrix")
         return out
 
@@ -223,7 +223,7 @@ class Recommender:
         # parity with the numba build itself stays unpinned.
         final = predict.fill_predictions(self.ratings, res.src, res.dst, res.val, user_sim, QUERY_WEIGHT, USER_WEIGHT,
                                          DEFAULT_MEAN, self.device, sum_order=self.sum_order)
-        final = final.cpu().numpy()
+        final = ops.to_host(final)
         self._log(str(round(time.time() - t0, 3)) + "s for weighted averages")
         finalPredictions = pd.DataFrame(final, columns=self.queriesIDs, index=self.usersIDs).astype(int)
         scores_missed = np.array(np.where(finalPredictions == 0)).T

