@@ -119,8 +119,10 @@ def algorithmic_bytes_per_step(w):
         "row_unique_gather": 16 * un,
         "region_unique": 8 * em + 8 * un,             # the same step, one workgroup per 2^g consecutive queries
         "region_gather": 16 * un,
-        # two signature rows + pair word in; score + two edge keys out
-        "score_pairs": (2 * sb * P + 8 + 4 + (8 if sel else 16)) * un,
+        # the pairs are sorted (i, j) and the kernel keeps / re-finds the first row while i does not change: the second
+        # row of every pair + the first row once per RUN of equal i (w["first_rows"]; = un when unknown, i.e. two rows
+        # per pair, SURVEY 8d's count) + pair word in; score + reverse word (or two edge keys) out
+        "score_pairs": (sb * P + 8 + 4 + (8 if sel else 16)) * un + sb * P * w.get("first_rows", un),
         "topk_count": 8 * 2 * un,
         "topk_fill": 8 * 2 * un + 12 * kept,
         # select form: run starts of both lists (words in, nq + 1 starts out, twice); every edge reads its own
@@ -317,7 +319,8 @@ def main():
                  P=P, b=b, nnz=nnz, emitted=int(res.stats.get("emitted_pairs", 0)), unique=int(res.pairs.numel()),
                  kept=int(res.src.numel()), sig_bytes=2 if res.sig.dtype == torch.int16 else 4,
                  group_bits=int(res.stats.get("group_bits", 0)), part_bits=int(res.stats.get("part_bits", 8)),
-                 topk=("select" if sharded and world > 1 else res.stats.get("topk", "select")))
+                 topk=("select" if sharded and world > 1 else res.stats.get("topk", "select")),
+                 first_rows=(int((torch.diff(res.pairs >> 32) != 0).sum().item()) + 1) if res.pairs.numel() else 0)
         ab = algorithmic_bytes_per_step(w)
         sb_tab = 2 if D <= 65536 else 4
         traffic, traffic_src, traffic_why = load_traffic(nq_total, P, b) if not sharded else ({}, None, "N > 1")

@@ -200,6 +200,16 @@ __device__ static inline uint64_t row_sum_u64(uint64_t v) {
   return v;
 }
 
+// a chunk with a value >= 0x8000 (D > 32768, or the 0xFFFF = -1 of an empty answer set): element by element in 64 bits.
+// Not inlined: inlined, the compiler unpacks the first row's elements where that row is LOADED (it changes only every few
+// pairs), which costs eight registers and -- worse -- a wait for ALL outstanding loads right behind the predicated load.
+__device__ static __attribute__((noinline)) uint64_t chunk_dot_wide(u16x8 x, u16x8 y) {
+  int64_t d = 0;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) d += c16(x[e]) * c16(y[e]);
+  return (uint64_t)d;
+}
+
 // exact dot product of two 8-value chunks of compact rows (see score_pairs_kernel)
 __device__ static inline uint64_t chunk_dot(u16x8 x, u16x8 y) {
   const u32x4 xw = __builtin_bit_cast(u32x4, x), yw = __builtin_bit_cast(u32x4, y);
@@ -211,22 +221,22 @@ __device__ static inline uint64_t chunk_dot(u16x8 x, u16x8 y) {
     s1 = __builtin_amdgcn_udot2(__builtin_shufflevector(x, x, 6, 7), __builtin_shufflevector(y, y, 6, 7), s1, false);
     return (uint64_t)s0 + (uint64_t)s1;
   }
-  int64_t d = 0;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) d += c16(x[e]) * c16(y[e]);
-  return (uint64_t)d;
+  return chunk_dot_wide(x, y);
 }
 
 #ifndef QR_SCORE_PF
-#define QR_SCORE_PF 2   // second rows requested ahead of the one being summed
+#define QR_SCORE_PF 1   // pairs whose rows are requested ahead of the one being summed (1: 2.25 ms at 10 M, 2 - 4: 2.45)
 #endif
 constexpr int SCORE_PF = QR_SCORE_PF;
 
 #ifndef QR_SCORE_OCC
 #define QR_SCORE_OCC 8   // workgroups of 4 waves per CU the register budget is held to (8: 64 VGPRs)
 #endif
+#ifndef QR_SCORE_OCC2
+#define QR_SCORE_OCC2 5  // the same for rows of 256 values (twice the row registers: 5 -> 96 VGPRs)
+#endif
 template <int CH>
-__global__ __launch_bounds__(256, QR_SCORE_OCC) void score_runs_kernel(const uint16_t *__restrict__ sig, const int64_t *__restrict__ norm2,
+__global__ __launch_bounds__(256, CH == 1 ? QR_SCORE_OCC : QR_SCORE_OCC2) void score_runs_kernel(const uint16_t *__restrict__ sig, const int64_t *__restrict__ norm2,
                                                          const uint64_t *__restrict__ pairs, int64_t n,
                                                          int32_t *__restrict__ milli, double *__restrict__ cosv,
                                                          uint64_t *__restrict__ edges, int id_bits,
@@ -237,7 +247,6 @@ __global__ __launch_bounds__(256, QR_SCORE_OCC) void score_runs_kernel(const uin
   constexpr int NB = SCORE_PF + 1;   // row buffers in rotation
   const int lig = threadIdx.x & (SCORE_LPP - 1);
   const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / SCORE_LPP;
-  const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) / SCORE_LPP;
   const int64_t nchunks = (n + SCORE_LPP - 1) / SCORE_LPP;
   auto row_of = [&](uint32_t id) -> const uint16_t * {
     return (id < split ? sig + (size_t)id * P : sig_b + (size_t)(id - split) * P) + lig * 8;
@@ -246,16 +255,14 @@ __global__ __launch_bounds__(256, QR_SCORE_OCC) void score_runs_kernel(const uin
 #pragma unroll
     for (int k = 0; k < CH; ++k) dst[k] = *reinterpret_cast<const u16x8 *>(p + k * 128);
   };
-  int64_t c = group;
-  uint64_t pw_next = (c < nchunks && c * SCORE_LPP + lig < n) ? pairs[c * SCORE_LPP + lig] : 0ull;
-  for (; c < nchunks; c += ngroups) {   // (a group's trip count is its own: nothing below crosses DPP rows)
+  // ONE chunk per group and launch: no chunk loop for the compiler to hoist 16 lane masks and half a dozen 64-bit
+  // induction variables out of (they did not fit 64 registers next to the row buffers and went to scratch: 5.8 ms)
+  {
+    const int64_t c = group;
+    if (c >= nchunks) return;   // (whole DPP rows leave together)
     const int64_t t = c * SCORE_LPP + lig;
     const bool live = t < n;
-    const uint64_t pw = pw_next;
-    {
-      const int64_t cn = c + ngroups;
-      pw_next = (cn < nchunks && cn * SCORE_LPP + lig < n) ? pairs[cn * SCORE_LPP + lig] : 0ull;
-    }
+    const uint64_t pw = live ? pairs[t] : 0ull;
     const uint32_t my_i = (uint32_t)(pw >> 32), my_j = (uint32_t)pw;
     int64_t na = 0, nb = 0;
     if (live) {
@@ -263,34 +270,54 @@ __global__ __launch_bounds__(256, QR_SCORE_OCC) void score_runs_kernel(const uin
       nb = my_j < split ? norm2[my_j] : norm2_b[my_j - split];
     }
     uint64_t my_dot = 0;
-    u16x8 a[CH], cb[NB][CH];
-    uint32_t cur_i;
+    // rows in rotation: pair V's two rows are requested together, PF pairs ahead of the one being summed (the counter
+    // that orders the waits is in issue order: a first row requested LATER than the second rows already in flight
+    // would make its consumer wait for all of them).  The first row of pair V is a copy of pair V - 1's unless i changed.
+    u16x8 ab[NB][CH], cb[NB][CH];
 #define QR_ROW_I(U) row_bcast_u32<(U)>(my_i)
 #define QR_ROW_J(U) row_bcast_u32<(U)>(my_j)
-    cur_i = QR_ROW_I(0);
-    load_row(a, row_of(cur_i));
-    // prologue: the second rows of pairs 0 .. PF - 1
-#define QR_PRO(U) \
-    if ((U) < SCORE_PF) load_row(cb[(U) % NB], row_of(QR_ROW_J(U)));
-    QR_PRO(0) QR_PRO(1) QR_PRO(2) QR_PRO(3)
-#undef QR_PRO
+#ifndef QR_SCORE_AREUSE
+#define QR_SCORE_AREUSE 0
+#endif
+#if QR_SCORE_AREUSE   /* first row copied from the previous pair's unless i changed (the copy waits for that row) */
+#define QR_REQ(V)                                                                           \
+    if ((V) < SCORE_LPP) {                                                                  \
+      if ((V) == 0) {                                                                       \
+        load_row(ab[0], row_of(QR_ROW_I(0)));                                               \
+      } else {                                                                              \
+        const uint32_t vi = QR_ROW_I((V) % SCORE_LPP), pi = QR_ROW_I(((V) + SCORE_LPP - 1) % SCORE_LPP); \
+        _Pragma("unroll") for (int k = 0; k < CH; ++k) ab[(V) % NB][k] = ab[((V) + NB - 1) % NB][k]; \
+        if (vi != pi) load_row(ab[(V) % NB], row_of(vi));                                   \
+      }                                                                                     \
+      load_row(cb[(V) % NB], row_of(QR_ROW_J((V) % SCORE_LPP)));                            \
+    }
+#else                 /* both rows of every pair requested (a repeated first row is a cache hit) */
+#define QR_REQ(V)                                                                           \
+    if ((V) < SCORE_LPP) {                                                                  \
+      load_row(ab[(V) % NB], row_of(QR_ROW_I((V) % SCORE_LPP)));                            \
+      load_row(cb[(V) % NB], row_of(QR_ROW_J((V) % SCORE_LPP)));                            \
+    }
+#endif
     static_assert(SCORE_PF >= 1 && SCORE_PF <= 4, "prefetch depth");
+    QR_REQ(0)
+    if (SCORE_PF > 1) { QR_REQ(1) }
+    if (SCORE_PF > 2) { QR_REQ(2) }
+    if (SCORE_PF > 3) { QR_REQ(3) }
 #define QR_STEP(U)                                                                          \
     {                                                                                       \
-      if ((U) + SCORE_PF < SCORE_LPP) load_row(cb[((U) + SCORE_PF) % NB], row_of(QR_ROW_J(((U) + SCORE_PF) % SCORE_LPP))); \
+      QR_REQ((U) + SCORE_PF)                                                                \
       uint64_t part = 0;                                                                    \
-      _Pragma("unroll") for (int k = 0; k < CH; ++k) part += chunk_dot(a[k], cb[(U) % NB][k]); \
+      _Pragma("unroll") for (int k = 0; k < CH; ++k) part += chunk_dot(ab[(U) % NB][k], cb[(U) % NB][k]); \
       const uint64_t tot = row_sum_u64(part);                                               \
       if (lig == (U)) my_dot = tot;                                                         \
-      if ((U) + 1 < SCORE_LPP) {                                                            \
-        const uint32_t ni = QR_ROW_I(((U) + 1) % SCORE_LPP);                                \
-        if (ni != cur_i) load_row(a, row_of(ni));                                           \
-        cur_i = ni;                                                                         \
-      }                                                                                     \
+      asm volatile("" : "+v"(my_dot)); /* materialised now: the compiler would otherwise keep all 16 totals and \
+                                          pick one at the end (32 registers, spilled) */    \
+      __builtin_amdgcn_sched_barrier(0); /* the loads stay where they are written: PF pairs ahead, not all 16 */ \
     }
     QR_STEP(0) QR_STEP(1) QR_STEP(2) QR_STEP(3) QR_STEP(4) QR_STEP(5) QR_STEP(6) QR_STEP(7)
     QR_STEP(8) QR_STEP(9) QR_STEP(10) QR_STEP(11) QR_STEP(12) QR_STEP(13) QR_STEP(14) QR_STEP(15)
 #undef QR_STEP
+#undef QR_REQ
 #undef QR_ROW_I
 #undef QR_ROW_J
     if (live) {
@@ -351,8 +378,8 @@ static int score_launch(const void *sig, const void *sig_b, int64_t split, int32
       g_score_runs = !(e && e[0] == '0');
     }
     if (g_score_runs && aligned && norm2 && (P == 128 || P == 256) && (sig_b == nullptr || norm2_b)) {
-      int64_t rb = ceil_div64(ceil_div64(n, SCORE_LPP), groups_per_block);
-      if (rb > 256 * 8) rb = 256 * 8;   // eight workgroups per CU, each group walking its chunks
+      const int64_t rb = ceil_div64(ceil_div64(n, SCORE_LPP), groups_per_block);   // one chunk of 16 pairs per group
+      QR_CHECK_ARG(rb <= 2147483647ll, "qrlsh_score_pairs: too many pairs for one launch");
       const dim3 rgrid((unsigned)rb);
       if (P == 128)
         QR_LAUNCH("score_pairs", (score_runs_kernel<1>), rgrid, block, 0, st, s16, norm2, pairs, n, milli_out, cos_out,
