@@ -415,6 +415,18 @@ int qrlsh_predict(const int32_t *ratings, int64_t nu, int64_t nq, const int64_t 
 int qrlsh_center_rows(const int32_t *ratings, int64_t nu, int64_t nq, int64_t nq_stride, int32_t *out,
                       void *stream);
 
+/* The clustering features of the same step (recommender.py:226-234: StandardScaler().fit_transform(ratings), then
+ * PCA(min(r, c, 200)).fit(.).transform(.)) for a matrix with far more columns (queries) than rows (users): column
+ * statistics as StandardScaler computes them (mean_out[nq]; inv_scale_out[nq] = 1 / scale, scale = sqrt(population
+ * variance), 1 for constant columns) and the Gram matrix gram_out[nu][nu] = Z Z^T of the standardized matrix
+ * Z = (ratings - mean) * inv_scale, in float64 on the matrix cores (v_mfma_f64_16x16x4_f64), the ratings read as
+ * integers and standardized while they are staged (Z is never materialised), summed over column slices in a fixed
+ * order (deterministic).  The PCA scores are U_k sqrt(lambda_k) of gram's eigen-decomposition (qrlsh/users.py).
+ * workspace: qrlsh_user_gram_workspace_bytes(nu, nq) (the per-slice partial matrices). */
+size_t qrlsh_user_gram_workspace_bytes(int64_t nu, int64_t nq);
+int qrlsh_user_gram(const int32_t *ratings, int64_t nu, int64_t nq, double *mean_out, double *inv_scale_out,
+                    double *gram_out, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- multi-GPU, "sets" mode: answer sets of chosen queries out of the replicated per-shard CSR arrays ------------
  * Every rank holds every shard's answer sets as an all-gather delivered them: offs[world][nql + 1] (off_bytes = 4 or 8)
  * and rows[world][max_nnz] (row_bytes = 2: unsigned 16-bit row ids, tables of at most 65536 rows; or 4), shard g =

@@ -66,3 +66,151 @@ QRLSH_EXPORT int qrlsh_center_rows(const int32_t *ratings, int64_t nu, int64_t n
   QR_LAUNCH_CHECK("qrlsh_center_rows");
   return QRLSH_OK;
 }
+
+// ---- N4, the clustering features (round 4): StandardScaler + PCA scores on the device ---------------------------------
+// recommender.py:226-234: normScores = StandardScaler().fit_transform(ratings); PCA(min(r, c, 200)).fit(.).transform(.)
+// on a (users x queries) matrix with users << queries (2000 x 100 000 on the bench shape: 6.9 s of scikit-learn on
+// the host, of a step whose device part takes 3 ms).  The PCA scores of a matrix with far more columns than rows come
+// from its GRAM matrix: with Z the standardized matrix (column means 0), G = Z Z^T (users x users) = U S^2 U^T and the
+// scores are U_k S_k -- a 2000 x 100 000 x 2000 float64 product, the one GEMM-shaped piece of this repository, done on
+// the matrix cores (v_mfma_f64_16x16x4_f64) with the standardization fused into the operand staging (the ratings are
+// read as the integers they are: Z is never materialised).  The eigen-decomposition of the small G and BIRCH stay with
+// library calls (qrlsh/users.py).
+//
+// column statistics exactly as scikit-learn's StandardScaler computes them (sklearn.utils.extmath.
+// _incremental_mean_and_var, first batch): T = sum / n (rows added in order), d = x - T, var = (sum d^2 - (sum d)^2 / n) / n;
+// a feature is constant when var <= n eps var + (n mean eps)^2 (sklearn.preprocessing._data._is_constant_feature) and
+// keeps scale 1; scale = sqrt(var), and a scale below 10 eps becomes 1 too.  inv_scale = 1 / scale.
+__global__ __launch_bounds__(256) void column_stats_kernel(const int32_t *__restrict__ ratings, int64_t nu, int64_t nq,
+                                                           double *__restrict__ mean, double *__restrict__ inv_scale) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nq) return;
+  double sum = 0.0;
+  for (int64_t r = 0; r < nu; ++r) sum += (double)ratings[r * nq + c];
+  const double n = (double)nu, T = sum / n;
+  double corr = 0.0, ss = 0.0;
+  for (int64_t r = 0; r < nu; ++r) {
+    const double d = (double)ratings[r * nq + c] - T;
+    corr += d;
+    ss += d * d;
+  }
+  double var = (ss - corr * corr / n) / n;
+  const double eps = 2.220446049250313e-16;
+  const double ub = n * eps * var + (n * T * eps) * (n * T * eps);
+  double scale = var <= ub ? 1.0 : sqrt(var);
+  if (scale < 10.0 * eps) scale = 1.0;
+  mean[c] = T;
+  inv_scale[c] = 1.0 / scale;
+}
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+constexpr int GR_T = 128;          // users per tile side (a workgroup owns a GR_T x GR_T tile of G over one K slice)
+constexpr int GR_K = 32;           // columns staged per step
+constexpr int GR_RS = GR_T + 1;    // row stride (doubles) of the [k][user] images: the staging writes of a wave land in 32 banks
+
+// partial[s][i][j] (tile pairs ti <= tj only) = sum over the columns of slice s of z_i z_j, z = (x - mean) * inv_scale.
+// 256 threads = 4 waves, wave w owns the 64 x 64 quadrant (w >> 1, w & 1) as 4 x 4 MFMA tiles of 16 x 16.
+// f64 MFMA operand maps: A[row = lane & 15][k = lane >> 4], B[k = lane >> 4][col = lane & 15]; D: col = lane & 15,
+// row = (lane >> 4) + 4 * reg.
+__global__ __launch_bounds__(256, 1) void user_gram_kernel(const int32_t *__restrict__ ratings, int64_t nu, int64_t nq,
+                                                           const double *__restrict__ mean,
+                                                           const double *__restrict__ inv_scale, int64_t slice_cols,
+                                                           int ntile, double *__restrict__ partial) {
+  __shared__ double za[GR_K][GR_RS], zb[GR_K][GR_RS];
+  // tile pair (ti <= tj) from the linear index
+  int ti = 0, rem = blockIdx.x;
+  while (rem >= ntile - ti) {
+    rem -= ntile - ti;
+    ++ti;
+  }
+  const int tj = ti + rem;
+  const int64_t i0 = (int64_t)ti * GR_T, j0 = (int64_t)tj * GR_T;
+  const int64_t c_lo = (int64_t)blockIdx.y * slice_cols, c_hi = min(nq, c_lo + slice_cols);
+  const int t = threadIdx.x, lane = t & (WAVE - 1), w = t >> 6;
+  const int wi = w >> 1, wj = w & 1;
+  const bool diag = ti == tj;
+  f64x4 acc[4][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = f64x4{0.0, 0.0, 0.0, 0.0};
+  const int kk = t & (GR_K - 1), r0 = t >> 5;   // staging: thread = (column kk of the step, rows r0, r0 + 8, ...)
+  for (int64_t c0 = c_lo; c0 < c_hi; c0 += GR_K) {
+    const int64_t col = c0 + kk;
+    const bool cok = col < c_hi;
+    const double mu = cok ? mean[col] : 0.0, is = cok ? inv_scale[col] : 0.0;
+#pragma unroll 4
+    for (int r = r0; r < GR_T; r += 256 / GR_K) {
+      const int64_t ui = i0 + r, uj = j0 + r;
+      za[kk][r] = (cok && ui < nu) ? ((double)ratings[ui * nq + col] - mu) * is : 0.0;
+      if (!diag) zb[kk][r] = (cok && uj < nu) ? ((double)ratings[uj * nq + col] - mu) * is : 0.0;
+    }
+    __syncthreads();
+    const double (*zbb)[GR_RS] = diag ? za : zb;
+#pragma unroll
+    for (int ks = 0; ks < GR_K / 4; ++ks) {
+      const int k = ks * 4 + (lane >> 4);
+      double a[4], b[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) a[m] = za[k][wi * 64 + m * 16 + (lane & 15)];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) b[n] = zbb[k][wj * 64 + n * 16 + (lane & 15)];
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  double *out = partial + (size_t)blockIdx.y * (size_t)nu * (size_t)nu;
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int64_t row = i0 + wi * 64 + m * 16 + (lane >> 4) + 4 * reg, colj = j0 + wj * 64 + n * 16 + (lane & 15);
+        if (row < nu && colj < nu) out[row * nu + colj] = acc[m][n][reg];
+      }
+}
+
+// G[i][j] = G[j][i] = sum over the slices, in slice order (deterministic), of the tile pairs ti <= tj
+__global__ __launch_bounds__(256) void gram_reduce_kernel(const double *__restrict__ partial, int64_t nu, int nslices,
+                                                          double *__restrict__ gram) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nu * nu) return;
+  const int64_t i = idx / nu, j = idx % nu;
+  const int64_t a = i / GR_T <= j / GR_T ? i : j, b = i / GR_T <= j / GR_T ? j : i;   // the stored orientation
+  double s = 0.0;
+  for (int k = 0; k < nslices; ++k) s += partial[(size_t)k * nu * nu + a * nu + b];
+  gram[idx] = s;
+}
+
+QRLSH_EXPORT size_t qrlsh_user_gram_workspace_bytes(int64_t nu, int64_t nq) {
+  if (nu <= 0 || nq <= 0) return 16;
+  const int64_t slices = nq >= 65536 ? 16 : nq >= 4096 ? 4 : 1;
+  return (size_t)slices * (size_t)nu * (size_t)nu * sizeof(double);
+}
+
+QRLSH_EXPORT int qrlsh_user_gram(const int32_t *ratings, int64_t nu, int64_t nq, double *mean_out, double *inv_scale_out,
+                                 double *gram_out, void *workspace, size_t workspace_bytes, void *stream) {
+  QR_CHECK_ARG(nu > 0 && nq > 0 && nu < (1ll << 20), "qrlsh_user_gram: bad sizes nu=%lld nq=%lld", (long long)nu, (long long)nq);
+  QR_CHECK_ARG(ratings && mean_out && inv_scale_out && gram_out && workspace, "qrlsh_user_gram: null pointer");
+  if (workspace_bytes < qrlsh_user_gram_workspace_bytes(nu, nq)) {
+    qrlsh_set_error("qrlsh_user_gram: workspace %zu < %zu bytes", workspace_bytes, qrlsh_user_gram_workspace_bytes(nu, nq));
+    return QRLSH_EWORKSPACE;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int slices = nq >= 65536 ? 16 : nq >= 4096 ? 4 : 1;
+  const int64_t slice_cols = ceil_div64(ceil_div64(nq, slices), GR_K) * GR_K;
+  const int ntile = (int)ceil_div64(nu, GR_T);
+  QR_LAUNCH("user_colstats", column_stats_kernel, dim3((unsigned)ceil_div64(nq, 256)), dim3(256), 0, st, ratings, nu, nq,
+            mean_out, inv_scale_out);
+  QR_LAUNCH("user_gram", user_gram_kernel, dim3((unsigned)(ntile * (ntile + 1) / 2), (unsigned)slices), dim3(256), 0, st,
+            ratings, nu, nq, (const double *)mean_out, (const double *)inv_scale_out, slice_cols, ntile,
+            static_cast<double *>(workspace));
+  QR_LAUNCH("user_gram_reduce", gram_reduce_kernel, dim3((unsigned)ceil_div64(nu * nu, 256)), dim3(256), 0, st,
+            (const double *)workspace, nu, slices, gram_out);
+  QR_LAUNCH_CHECK("qrlsh_user_gram");
+  return QRLSH_OK;
+}

@@ -93,6 +93,8 @@ SIGNATURES = {
     "qrlsh_predict": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i32, ctypes.c_double, ctypes.c_double,
                                      ctypes.c_double, _i32, _vp, _vp, _i32, _vp, _sz, _vp]),
     "qrlsh_center_rows": (ctypes.c_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
+    "qrlsh_user_gram_workspace_bytes": (_sz, [_i64, _i64]),
+    "qrlsh_user_gram": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "qrlsh_gather_sets_workspace_bytes": (_sz, [_i64]),
     "qrlsh_gather_sets_count": (ctypes.c_int, [_vp, _i64, _vp, _i32, _i64, _i64, _vp, _vp, _sz, _vp]),
     "qrlsh_gather_sets_fill": (ctypes.c_int, [_vp, _i64, _vp, _i32, _vp, _i32, _i64, _i64, _vp, _vp, _vp]),

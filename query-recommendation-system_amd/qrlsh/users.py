@@ -1,7 +1,9 @@
 """N4 -- user similarity on the device (Recommender.compute_userSimilarities, recommender.py:216-290).
 
-cluster_labels(): the reference's scikit-learn pipeline (StandardScaler -> PCA -> BIRCH, :226-261) on the
-host, exactly as the reference calls it -- the library IS the reference's algorithm for that step.
+cluster_labels(): the reference's scikit-learn pipeline (StandardScaler -> PCA -> BIRCH, :226-261): on the host
+exactly as the reference calls it, or (device=...) with StandardScaler + PCA on the device -- the Gram matrix of the
+standardized ratings on the matrix cores (qrlsh_user_gram), its eigen-decomposition, scores = U sqrt(lambda) -- and
+only BIRCH (2000 points of 200 dimensions) left to the reference's scikit-learn call.
 user_similarities(): everything after it (:263-288) on the device, with the hot path's own kernels: rows
 centred with the reference's integer truncation (qrlsh_center_rows), the pairs of every cluster from the
 bucket machinery (labels = a one-band key), cosine by qrlsh_score_pairs on the integer rows, negatives
@@ -21,16 +23,55 @@ def max_candidates(nu):
     return round(math.log(nu, 1.5))
 
 
-def cluster_labels(ratings):
-    """recommender.py:226-261 -> int64 labels [nu]; clusters of a single user share the label n_clusters"""
-    from sklearn.cluster import Birch
+def pca_features_host(ratings):
+    """recommender.py:226-234 with the reference's own scikit-learn calls on the host -> float64 [nu, n_comps]"""
     from sklearn.decomposition import PCA
     from sklearn.preprocessing import StandardScaler
     ratings = np.asarray(ratings)
+    feats = StandardScaler().fit_transform(ratings)
+    return PCA(n_components=min(feats.shape[0], feats.shape[1], 200)).fit(feats).transform(feats)
+
+
+def standardized_gram(ratings):
+    """int32 [nu][nq] device tensor -> (mean [nq], 1 / scale [nq], G [nu][nu]) float64 on the device: the column
+    statistics of StandardScaler and G = Z Z^T of the standardized matrix Z (qrlsh_user_gram: matrix cores, the
+    standardization fused into the operand staging; Z is never materialised)"""
+    lib = _lib.load()
+    nu, nq = ratings.shape
+    dev = ratings.device
+    mean = torch.empty((nq,), dtype=torch.float64, device=dev)
+    inv = torch.empty((nq,), dtype=torch.float64, device=dev)
+    gram = torch.empty((nu, nu), dtype=torch.float64, device=dev)
+    ws = ops._ws(lib.qrlsh_user_gram_workspace_bytes(nu, nq), dev)
+    _lib.check(lib.qrlsh_user_gram(_ptr(ratings), nu, nq, _ptr(mean), _ptr(inv), _ptr(gram), _ptr(ws), ws.numel(), _stream()))
+    return mean, inv, gram
+
+
+def pca_features(ratings, device="cuda"):
+    """The same features on the device: the PCA scores of a (users x queries) matrix with users << queries are
+    U_k sqrt(lambda_k) of the eigen-decomposition of its Gram matrix (standardized_gram); the small symmetric
+    eigenproblem is a library call (torch.linalg.eigh on the device).  Equal to scikit-learn's transform(X) up to the
+    sign of each component and float64 rounding -- BIRCH (Euclidean distances) does not see either.
+    -> float64 device tensor [nu, n_comps], components by descending variance"""
+    r = ratings if isinstance(ratings, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(ratings), dtype=np.int32))
+    r = r.to(device=device, dtype=torch.int32).contiguous()
+    nu, nq = r.shape
+    k = min(nu, nq, 200)
+    _, _, gram = standardized_gram(r)
+    lam, vec = torch.linalg.eigh(gram)               # ascending eigenvalues
+    lam_k = lam[nu - k:].flip(0).clamp_min(0.0)
+    return vec[:, nu - k:].flip(1) * lam_k.sqrt()
+
+
+def cluster_labels(ratings, device=None):
+    """recommender.py:226-261 -> int64 labels [nu]; clusters of a single user share the label n_clusters.
+    device=None: the whole step with the reference's scikit-learn calls on the host.  device="cuda": StandardScaler +
+    PCA on the device (pca_features), BIRCH -- 200-dimensional points, milliseconds -- with the reference's own
+    scikit-learn call on the host."""
+    from sklearn.cluster import Birch
     nu = ratings.shape[0]
     n_clusters = round(nu ** (1 / 1.3))
-    feats = StandardScaler().fit_transform(ratings)
-    feats = PCA(n_components=min(feats.shape[0], feats.shape[1], 200)).fit(feats).transform(feats)
+    feats = pca_features_host(ratings) if device is None else ops.to_host(pca_features(ratings, device))
     label = Birch(n_clusters=n_clusters).fit(feats).predict(feats).astype(np.int64)
     sizes = np.bincount(label)
     label[np.isin(label, np.flatnonzero(sizes == 1))] = n_clusters     # pool the singletons (:259-261)

@@ -64,6 +64,7 @@ class Recommender:
         if self.verbose:
             print(*a)
 
+    cluster_on_device = True   # StandardScaler + PCA of compute_userSimilarities on the device (False: scikit-learn on the host)
     sum_order = "sequential"   # order of weighted_average's two np.sum calls, see compute_scores
 
     def init(self, users, queries, queriesIDs, dataset, ratings):
@@ -198,7 +199,9 @@ class Recommender:
         n_clusters = round(nu ** (1 / 1.3))
         self._log("\nMax user candidates: {}, Total users: {}".format(top, nu))
         self._log("\nCluster count: {}, Total users: {}".format(n_clusters, nu))
-        label = users.cluster_labels(self.ratings)
+        # StandardScaler + PCA on the device (Gram matrix on the matrix cores), BIRCH by the reference's own
+        # scikit-learn call; cluster_on_device = False: the whole clustering on the host, as the reference runs it
+        label = users.cluster_labels(self.ratings, device=self.device if self.cluster_on_device else None)
         pairs, milli = users.cluster_pair_scores(self.ratings, label, self.device)
         user_sim = users.reference_cut(pairs, milli, label, top)
         self._log("\n" + str(round(time.time() - t0, 3)) + "s for overall users_similarity scores")

