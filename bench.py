@@ -546,9 +546,22 @@ def secondary_figures(dev, table, P, b, D):
     ms4 = timed("user_similarities", run_n4, reps=3)
     npairs = int(sum(c * (c - 1) // 2 for c in np.bincount(labels.cpu().numpy())))
     sc = ms4.get("score_pairs", 0.0)
-    # the step of recommender.py:216-290 that precedes the device part and stays on the host: the reference's own
-    # scikit-learn clustering (StandardScaler -> PCA(200) -> BIRCH) of the same matrix, timed here so that the
-    # device milliseconds below are not read as the cost of compute_userSimilarities
+    # the step of recommender.py:216-290 that precedes the pair kernels: the clustering (StandardScaler -> PCA(200) ->
+    # BIRCH, :226-261).  Round 4: StandardScaler + PCA on the device (Gram matrix of the standardized ratings on the
+    # matrix cores, eigh, U sqrt(lambda): qrlsh.users.pca_features), BIRCH on its 2000 x 200 features by the
+    # reference's scikit-learn call on the host; the all-host form (the reference's own three calls) timed beside it
+    from sklearn.cluster import Birch
+    users.pca_features(rt, dev)                      # (first call: rocSOLVER / allocator warm-up)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    feats = users.pca_features(rt, dev)
+    torch.cuda.synchronize()
+    dev_feat_s = time.perf_counter() - t0
+    ms_g = timed("pca_features", lambda: users.standardized_gram(rt), reps=3)
+    fh = feats.cpu().numpy()
+    t0 = time.perf_counter()
+    dlab = Birch(n_clusters=round(nu ** (1 / 1.3))).fit(fh).predict(fh)
+    birch_s = time.perf_counter() - t0
     t0 = time.perf_counter()
     hlab = users.cluster_labels(ratings)
     host_cluster_s = time.perf_counter() - t0
@@ -556,13 +569,20 @@ def secondary_figures(dev, table, P, b, D):
         host_cores = len(os.sched_getaffinity(0))
     except AttributeError:
         host_cores = os.cpu_count() or 1
+    gram_ms = ms_g.get("user_gram", 0.0)
     out["next_N4_user_similarity"] = {
-        "host_clustering_s": round(host_cluster_s, 3),
-        "host_clustering": "scikit-learn StandardScaler + PCA(200) + BIRCH on the host (%d cores available), the "
-                           "reference's own call (recommender.py:226-261); it found %d clusters (largest %d users) in "
-                           "this random matrix -- the device figures below use 40 synthetic clusters of ~50 users so "
-                           "that the pair kernels have work" % (host_cores, len(np.unique(hlab)), int(np.bincount(hlab).max())),
-        "total_s_host_plus_device": round(host_cluster_s + sum(ms4.values()) * 1e-3, 3),
+        "host_clustering_s": round(dev_feat_s + birch_s, 3),
+        "clustering": {"device_standardize_pca_s": round(dev_feat_s, 4), "host_birch_s": round(birch_s, 3),
+                       "gram_kernels_ms": {k: round(v, 4) for k, v in ms_g.items()},
+                       "gram_TFLOPs_f64": round(nu * (nu + 128) * nqq / (gram_ms * 1e-3) / 1e12, 1) if gram_ms else None,
+                       "all_host_scikit_learn_s": round(host_cluster_s, 3)},
+        "host_clustering": "StandardScaler + PCA(200) on the device (float64 MFMA Gram matrix of the standardized "
+                           "ratings + eigh), BIRCH by scikit-learn on the host (recommender.py:226-261); the reference's "
+                           "three scikit-learn calls on the host (%d cores available) take all_host_scikit_learn_s. "
+                           "This random matrix has no cluster structure (%d / %d clusters found, largest %d users) -- "
+                           "the device figures below use 40 synthetic clusters of ~50 users so that the pair kernels "
+                           "have work" % (host_cores, len(np.unique(dlab)), len(np.unique(hlab)), int(np.bincount(hlab).max())),
+        "total_s_host_plus_device": round(dev_feat_s + birch_s + sum(ms4.values()) * 1e-3, 3),
         "workload": "%d users x %d queries in 40 clusters: %d pairs of rows, K=%d" % (nu, nqq, npairs, Kn),
         "kernels_ms": {k: round(v, 4) for k, v in sorted(ms4.items(), key=lambda kv: -kv[1])[:6]},
         "device_ms_total": round(sum(ms4.values()), 4),
