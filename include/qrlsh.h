@@ -229,6 +229,28 @@ int qrlsh_region_unique_count(const uint64_t *grouped, int64_t n, int32_t group_
 int qrlsh_region_unique_fill(const uint64_t *tmp, int64_t n, int32_t group_bits, int64_t nids, const void *workspace,
                              uint64_t *out, void *stream);
 
+/* The same de-duplication WITHOUT the grouping sort: the region finish needs the words grouped by region (i >> group_bits)
+ * and nothing about the order inside a group, so the stable radix passes (a histogram pass, a scan and a scatter per 8
+ * bits) are replaced by a most-significant-digit-first partition into FIXED regions with one atomic reservation per
+ * (tile, digit): one read and one write of the words per level, two levels for up to 65536 regions.
+ * qrlsh_pair_regions_scatter deals the n emitted words into regions[r * cap ..) (counts[r] words each; cap =
+ * qrlsh_pair_regions_cap, buffers of qrlsh_pair_regions_words / _tmp_words words, counts of _count + 256 uint32);
+ * words_per_query: what a query of the populated id range emits on average (0: n / nids) -- sizes the regions (3 x the
+ * mean + 4096: i is the smaller id of a pair, so low ids carry up to twice the mean).  *overflow_out != 0: a region
+ * outgrew its capacity (group with qrlsh_sort_u64 instead).  qrlsh_pair_regions_words returns 0 when the id space has
+ * more than 65536 regions (not served).  qrlsh_region_unique_count_regions is qrlsh_region_unique_count on those
+ * regions (tmp: as many words as the region buffer); qrlsh_region_unique_fill follows it as usual. */
+size_t qrlsh_pair_regions_words(int64_t n, int64_t nids, int32_t group_bits, double words_per_query);
+size_t qrlsh_pair_regions_tmp_words(int64_t n, int64_t nids, int32_t group_bits, double words_per_query);
+int64_t qrlsh_pair_regions_cap(int64_t n, int64_t nids, int32_t group_bits, double words_per_query);
+int64_t qrlsh_pair_regions_count(int64_t n, int64_t nids, int32_t group_bits, double words_per_query);
+int qrlsh_pair_regions_scatter(const uint64_t *words, int64_t n, int32_t group_bits, int64_t nids, double words_per_query,
+                               uint64_t *tmp_regions, uint64_t *regions, uint32_t *counts, uint32_t *overflow_out,
+                               void *stream);
+int qrlsh_region_unique_count_regions(const uint64_t *regions, const uint32_t *counts, int64_t cap, int64_t n,
+                                      int32_t group_bits, int32_t id_bits, int64_t nids, uint64_t *tmp, void *workspace,
+                                      size_t workspace_bytes, uint64_t *total_overflow_out, void *stream);
+
 /* ---- a5: pair scoring ------------------------------------------------------------
  * Replaces the cosine of recommender.py:203-204 for one candidate pair:
  *     np.around(cosine_similarity([sig_i, sig_j])[0][1], 3)

@@ -898,13 +898,16 @@ __device__ static inline bool region_finish(const uint64_t *__restrict__ in, int
 
 __global__ __launch_bounds__(RG_THREADS, 8) void region_unique_kernel(const uint64_t *__restrict__ in,
                                                                       const uint64_t *__restrict__ starts,
+                                                                      const uint64_t *__restrict__ ends,
                                                                       uint64_t *__restrict__ tmp,
                                                                       uint64_t *__restrict__ counts,
                                                                       uint64_t *__restrict__ biglist,
                                                                       unsigned long long *__restrict__ nbig, int gbits,
                                                                       int jbits) {
   const int64_t region = blockIdx.x;
-  const int64_t s0 = (int64_t)starts[region], s1 = (int64_t)starts[region + 1];
+  // words of the region: [starts[r], ends[r]) -- ends = starts + 1 for words sorted by region, its own array for the
+  // fixed regions of qrlsh_pair_regions_scatter
+  const int64_t s0 = (int64_t)starts[region], s1 = (int64_t)ends[region];
   if (s0 == s1) {  // uniform
     if (threadIdx.x == 0) counts[region] = 0;
     return;
@@ -923,6 +926,7 @@ constexpr int RG_BIG_SEG = 12288;
 constexpr int RG_BIG_GRID = 256;
 __global__ __launch_bounds__(RG_THREADS, 4) void region_unique_big_kernel(const uint64_t *__restrict__ in,
                                                                           const uint64_t *__restrict__ starts,
+                                                                          const uint64_t *__restrict__ ends,
                                                                           uint64_t *__restrict__ tmp,
                                                                           uint64_t *__restrict__ counts,
                                                                           const uint64_t *__restrict__ biglist,
@@ -932,7 +936,7 @@ __global__ __launch_bounds__(RG_THREADS, 4) void region_unique_big_kernel(const 
   const unsigned long long nb = *nbig;
   for (unsigned long long e = blockIdx.x; e < nb; e += gridDim.x) {
     const int64_t region = (int64_t)biglist[e];
-    const int64_t s0 = (int64_t)starts[region], s1 = (int64_t)starts[region + 1];
+    const int64_t s0 = (int64_t)starts[region], s1 = (int64_t)ends[region];
     if (!region_finish<14, RG_BIG_SEG>(in, s0, s1, region, tmp, counts, gbits, jbits) && threadIdx.x == 0)
       atomicOr((unsigned long long *)overflow, 1ull);
   }
@@ -949,59 +953,95 @@ __global__ __launch_bounds__(256) void region_gather_kernel(const uint64_t *__re
   for (uint32_t k = threadIdx.x; k < cnt; k += 256) out[o0 + k] = src[k];
 }
 
-// workspace: starts[nregions + 1] | counts[nregions + 1] | biglist[nregions] | nbig | chunk totals of the scan
+// workspace: starts[nregions + 1] | counts[nregions + 1] | biglist[nregions] | nbig | chunk totals of the scan |
+//            ends[nregions + 1] (fixed-region form only)
 static int64_t region_count(int64_t nids, int gbits) { return (nids + (1ll << gbits) - 1) >> gbits; }
 
 QRLSH_EXPORT size_t qrlsh_region_unique_workspace_bytes(int64_t nids, int32_t group_bits) {
   if (nids <= 0 || group_bits < 0 || group_bits > 8) return 64;
   const int64_t nr = region_count(nids, group_bits);
-  return (size_t)(3 * (nr + 1) + ceil_div64(nr + 1, SCANL_CHUNK) + 2) * sizeof(uint64_t);
+  return (size_t)(4 * (nr + 1) + ceil_div64(nr + 1, SCANL_CHUNK) + 2) * sizeof(uint64_t);
 }
 
-QRLSH_EXPORT int qrlsh_region_unique_count(const uint64_t *grouped, int64_t n, int32_t group_bits, int32_t id_bits,
-                                           int64_t nids, uint64_t *tmp, void *workspace, size_t workspace_bytes,
-                                           uint64_t *total_overflow_out, void *stream) {
-  QR_CHECK_ARG(n >= 0 && total_overflow_out && nids > 0 && nids <= (1ll << 32), "qrlsh_region_unique_count: bad arguments");
+// spans of the fixed regions qrlsh_pair_regions_scatter fills: region r = words [r * cap, r * cap + counts[r])
+__global__ __launch_bounds__(256) void region_spans_kernel(const uint32_t *__restrict__ counts, int64_t nr, uint32_t cap,
+                                                           uint64_t *__restrict__ starts, uint64_t *__restrict__ ends) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > nr) return;
+  starts[r] = (uint64_t)r * cap;
+  ends[r] = (uint64_t)r * cap + (r < nr ? min(counts[r], cap) : 0u);
+}
+
+// shared body of the two count entry points.  regions_counts == NULL: `grouped` holds n words sorted by region (bounds by
+// binary search); else the fixed regions of qrlsh_pair_regions_scatter (region r at r * cap, regions_counts[r] words).
+static int region_unique_count_impl(const char *name, const uint64_t *grouped, int64_t n, const uint32_t *regions_counts,
+                                    uint32_t cap, int32_t group_bits, int32_t id_bits, int64_t nids, uint64_t *tmp,
+                                    void *workspace, size_t workspace_bytes, uint64_t *total_overflow_out, void *stream) {
+  QR_CHECK_ARG(n >= 0 && total_overflow_out && nids > 0 && nids <= (1ll << 32), "%s: bad arguments", name);
   // the 32-bit value (i's low bits, j) must never be the empty-slot marker 0xFFFFFFFF: either it has a spare
   // bit, or the largest j (nids - 1) is not all ones
   // (id_bits <= 31: the kernels build the j mask as (1u << id_bits) - 1)
   QR_CHECK_ARG(group_bits >= 0 && group_bits <= 8 && id_bits >= 1 && id_bits <= 31 && nids <= (1ll << id_bits) &&
                    (group_bits + id_bits < 32 || (group_bits + id_bits == 32 && nids < (1ll << id_bits))),
-               "qrlsh_region_unique_count: group_bits=%d / id_bits=%d (need group_bits <= 8, id_bits <= 31, group_bits + "
-               "id_bits <= 32)",
+               "%s: group_bits=%d / id_bits=%d (need group_bits <= 8, id_bits <= 31, group_bits + id_bits <= 32)", name,
                group_bits, id_bits);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (hipMemsetAsync(total_overflow_out, 0, 2 * sizeof(uint64_t), st) != hipSuccess) {
-    qrlsh_set_error("qrlsh_region_unique_count: hipMemsetAsync failed");
+    qrlsh_set_error("%s: hipMemsetAsync failed", name);
     return QRLSH_EHIP;
   }
   if (n == 0) return QRLSH_OK;
-  QR_CHECK_ARG(grouped && tmp && workspace, "qrlsh_region_unique_count: null pointer");
+  QR_CHECK_ARG(grouped && tmp && workspace, "%s: null pointer", name);
   if (workspace_bytes < qrlsh_region_unique_workspace_bytes(nids, group_bits)) {
-    qrlsh_set_error("qrlsh_region_unique_count: workspace %zu < %zu bytes", workspace_bytes,
+    qrlsh_set_error("%s: workspace %zu < %zu bytes", name, workspace_bytes,
                     qrlsh_region_unique_workspace_bytes(nids, group_bits));
     return QRLSH_EWORKSPACE;
   }
   const int64_t nr = region_count(nids, group_bits);
-  QR_CHECK_ARG(nr <= 2147483647ll, "qrlsh_region_unique_count: too many regions");
+  QR_CHECK_ARG(nr <= 2147483647ll, "%s: too many regions", name);
   uint64_t *starts = static_cast<uint64_t *>(workspace), *counts = starts + (nr + 1), *biglist = counts + (nr + 1);
   uint64_t *nbig = biglist + nr, *sums = nbig + 1;
+  uint64_t *ends = sums + ceil_div64(nr + 1, SCANL_CHUNK) + 1;
   if (hipMemsetAsync(counts + nr, 0, sizeof(uint64_t), st) != hipSuccess ||
       hipMemsetAsync(nbig, 0, sizeof(uint64_t), st) != hipSuccess) {
-    qrlsh_set_error("qrlsh_region_unique_count: hipMemsetAsync failed");
+    qrlsh_set_error("%s: hipMemsetAsync failed", name);
     return QRLSH_EHIP;
   }
-  QR_LAUNCH("region_bounds", region_bounds_kernel, dim3((unsigned)ceil_div64(nr + 1, 256)), dim3(256), 0, st, grouped, n,
-            32 + group_bits, nr, starts);
+  if (regions_counts) {
+    QR_LAUNCH("region_bounds", region_spans_kernel, dim3((unsigned)ceil_div64(nr + 1, 256)), dim3(256), 0, st, regions_counts,
+              nr, cap, starts, ends);
+  } else {
+    QR_LAUNCH("region_bounds", region_bounds_kernel, dim3((unsigned)ceil_div64(nr + 1, 256)), dim3(256), 0, st, grouped, n,
+              32 + group_bits, nr, starts);
+    ends = starts + 1;
+  }
   QR_LAUNCH("region_unique", region_unique_kernel, dim3((unsigned)nr), dim3(RG_THREADS), 0, st, grouped,
-            (const uint64_t *)starts, tmp, counts, biglist, reinterpret_cast<unsigned long long *>(nbig), group_bits,
-            id_bits);
+            (const uint64_t *)starts, (const uint64_t *)ends, tmp, counts, biglist,
+            reinterpret_cast<unsigned long long *>(nbig), group_bits, id_bits);
   QR_LAUNCH("region_unique_big", region_unique_big_kernel, dim3((unsigned)(nr < RG_BIG_GRID ? nr : RG_BIG_GRID)),
-            dim3(RG_THREADS), 0, st, grouped, (const uint64_t *)starts, tmp, counts, (const uint64_t *)biglist,
-            (const unsigned long long *)nbig, total_overflow_out + 1, group_bits, id_bits);
+            dim3(RG_THREADS), 0, st, grouped, (const uint64_t *)starts, (const uint64_t *)ends, tmp, counts,
+            (const uint64_t *)biglist, (const unsigned long long *)nbig, total_overflow_out + 1, group_bits, id_bits);
   qr_scan_u64(counts, nr + 1, total_overflow_out, sums, st);
-  QR_LAUNCH_CHECK("qrlsh_region_unique_count");
+  QR_LAUNCH_CHECK(name);
   return QRLSH_OK;
+}
+
+QRLSH_EXPORT int qrlsh_region_unique_count(const uint64_t *grouped, int64_t n, int32_t group_bits, int32_t id_bits,
+                                           int64_t nids, uint64_t *tmp, void *workspace, size_t workspace_bytes,
+                                           uint64_t *total_overflow_out, void *stream) {
+  return region_unique_count_impl("qrlsh_region_unique_count", grouped, n, nullptr, 0u, group_bits, id_bits, nids, tmp,
+                                  workspace, workspace_bytes, total_overflow_out, stream);
+}
+
+// The same from the fixed regions qrlsh_pair_regions_scatter filled (region r = regions[r * cap ..), counts[r] words, any
+// order): tmp must hold as many words as the region buffer; n = the number of words scattered (0: nothing to do).
+QRLSH_EXPORT int qrlsh_region_unique_count_regions(const uint64_t *regions, const uint32_t *counts, int64_t cap, int64_t n,
+                                                   int32_t group_bits, int32_t id_bits, int64_t nids, uint64_t *tmp,
+                                                   void *workspace, size_t workspace_bytes, uint64_t *total_overflow_out,
+                                                   void *stream) {
+  QR_CHECK_ARG(counts && cap > 0 && cap < (1ll << 32), "qrlsh_region_unique_count_regions: bad arguments");
+  return region_unique_count_impl("qrlsh_region_unique_count_regions", regions, n, counts, (uint32_t)cap, group_bits, id_bits,
+                                  nids, tmp, workspace, workspace_bytes, total_overflow_out, stream);
 }
 
 QRLSH_EXPORT int qrlsh_region_unique_fill(const uint64_t *tmp, int64_t n, int32_t group_bits, int64_t nids,

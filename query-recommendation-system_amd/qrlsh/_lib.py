@@ -64,6 +64,12 @@ SIGNATURES = {
     "qrlsh_region_unique_workspace_bytes": (_sz, [_i64, _i32]),
     "qrlsh_region_unique_count": (ctypes.c_int, [_vp, _i64, _i32, _i32, _i64, _vp, _vp, _sz, _vp, _vp]),
     "qrlsh_region_unique_fill": (ctypes.c_int, [_vp, _i64, _i32, _i64, _vp, _vp, _vp]),
+    "qrlsh_region_unique_count_regions": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i32, _i32, _i64, _vp, _vp, _sz, _vp, _vp]),
+    "qrlsh_pair_regions_words": (_sz, [_i64, _i64, _i32, ctypes.c_double]),
+    "qrlsh_pair_regions_tmp_words": (_sz, [_i64, _i64, _i32, ctypes.c_double]),
+    "qrlsh_pair_regions_cap": (_i64, [_i64, _i64, _i32, ctypes.c_double]),
+    "qrlsh_pair_regions_count": (_i64, [_i64, _i64, _i32, ctypes.c_double]),
+    "qrlsh_pair_regions_scatter": (ctypes.c_int, [_vp, _i64, _i32, _i64, ctypes.c_double, _vp, _vp, _vp, _vp, _vp]),
     "qrlsh_unique_count": (ctypes.c_int, [_vp, _i64, _vp, _sz, _vp, _vp]),
     "qrlsh_unique_fill": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp]),
     "qrlsh_row_norms": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp]),

@@ -399,16 +399,71 @@ def region_unique(grouped, group_bits, id_bits, nids):
     return out
 
 
-def unique_pairs(emitted, nq, stats=None, words_per_query=None):
+REGION_SCATTER_MAX_BYTES = 48 << 30    # the fixed-region grouping is skipped when its buffers would exceed this
+
+
+def region_unique_scattered(emitted, group_bits, id_bits, nids, words_per_query=0.0):
+    """Sorted unique pairs straight from the emitted words: dealt into fixed regions of 2^group_bits queries by two
+    histogram-free partition steps (qrlsh_pair_regions_scatter: nothing inside a region is ordered -- the region
+    finish does not need it), then the region finish on those regions.  -> (pairs, "") or (None, why): "cap" when a
+    region outgrew its capacity or the buffers would be too large (the caller then groups by sorting), "distinct" when
+    a region holds more distinct pairs than the finish's LDS set (sorting by region would meet the same: the caller
+    sorts everything)."""
+    lib = _lib.load()
+    _need(emitted, torch.int64, "emitted", 1)
+    n = emitted.numel()
+    if n == 0:
+        return emitted, ""
+    dev = emitted.device
+    wpq = float(words_per_query)
+    words = lib.qrlsh_pair_regions_words(n, nids, group_bits, wpq)
+    twords = lib.qrlsh_pair_regions_tmp_words(n, nids, group_bits, wpq)
+    if words == 0 or n >= (1 << 32) or (2 * words + twords) * 8 > REGION_SCATTER_MAX_BYTES:
+        return None, "cap"          # (words == 0: more than 65536 regions -- two levels of 256 digits do not reach)
+    cap = lib.qrlsh_pair_regions_cap(n, nids, group_bits, wpq)
+    nreg = lib.qrlsh_pair_regions_count(n, nids, group_bits, wpq)
+    regions = torch.empty((words,), dtype=torch.int64, device=dev)
+    tmpr = torch.empty((twords,), dtype=torch.int64, device=dev) if twords else None
+    counts = torch.empty((nreg + 256,), dtype=torch.int32, device=dev)
+    ovf = torch.empty((1,), dtype=torch.int32, device=dev)
+    _lib.check(lib.qrlsh_pair_regions_scatter(_ptr(emitted), n, int(group_bits), int(nids), wpq, _ptr(tmpr), _ptr(regions),
+                                              _ptr(counts), _ptr(ovf), _stream()))
+    del tmpr
+    tmp = torch.empty_like(regions)
+    ws = _ws(lib.qrlsh_region_unique_workspace_bytes(nids, group_bits), dev)
+    tot = torch.empty(2, dtype=torch.int64, device=dev)
+    _lib.check(lib.qrlsh_region_unique_count_regions(_ptr(regions), _ptr(counts), cap, n, int(group_bits), int(id_bits),
+                                                     int(nids), _ptr(tmp), _ptr(ws), ws.numel(), _ptr(tot), _stream()))
+    total, overflow = tot.tolist()          # (the stream is in order: the scatter's flag is final by now as well)
+    if int(ovf.item()):
+        return None, "cap"
+    if overflow:
+        return None, "distinct"
+    del regions
+    out = torch.empty((total,), dtype=torch.int64, device=dev)
+    _lib.check(lib.qrlsh_region_unique_fill(_ptr(tmp), n, int(group_bits), int(nids), _ptr(ws), _ptr(out), _stream()))
+    return out, ""
+
+
+def unique_pairs(emitted, nq, stats=None, words_per_query=None, scatter=True):
     """the Python set of lsh.py:41,53: sorted unique words of the emitted pairs (consumed).
-    words_per_query: emitted words per query id of the id space (default: emitted / nq)"""
+    words_per_query: emitted words per query id of the id space (default: emitted / nq).
+    scatter: group by the histogram-free fixed-region partition (default); False: by the stable radix sort."""
     ib = id_bits_for(nq)
     wpq = emitted.numel() / max(nq, 1) if words_per_query is None else words_per_query
     g = region_group_bits(ib, nq, wpq)
+    pairs = None
     if g is not None:
-        grouped = group_pairs_by_i(emitted, nq, g)
-        pairs = region_unique(grouped, g, ib, nq)
-        path = "regions-in-lds"
+        path, why = "regions-in-lds", "cap"
+        if scatter:
+            pairs, why = region_unique_scattered(emitted, g, ib, nq, wpq)
+            path = "regions-in-lds (scattered)"
+        if pairs is None and why == "distinct":
+            grouped = emitted                       # straight to the full sort below
+        elif pairs is None:
+            grouped = group_pairs_by_i(emitted, nq, g)
+            pairs = region_unique(grouped, g, ib, nq)
+            path = "regions-in-lds"
     else:
         g = row_group_bits(ib, wpq)
         grouped = group_pairs_by_i(emitted, nq, g)

@@ -231,6 +231,19 @@ def test_region_unique_equals_sorted_set(case, id_bits, g):
     got = ops.region_unique(dev(grouped.view(np.int64)), g, id_bits, nids)
     assert got is not None
     assert np.array_equal(u64(got), np.unique(words))
+    # the same straight from the unordered words: dealt into fixed regions by the histogram-free partition
+    # (qrlsh_pair_regions_scatter), the region finish on those.  The words sit in the first 30 000 of nids ids: told how
+    # many words a query emits, the regions are sized for that density; not told, they overflow ("cap") -- never a wrong list
+    wpq = len(words) / max(1, len(lens))
+    got, why = ops.region_unique_scattered(dev(words.view(np.int64)), g, id_bits, nids, words_per_query=wpq)
+    if -(-nids // (1 << g)) > 65536:           # more regions than two levels of 256 digits reach: not served
+        assert got is None and why == "cap"
+    elif case in ("hot", "big", "mixed"):      # single queries with tens of thousands of words outgrow any sensible region
+        assert (got is None and why == "cap") or np.array_equal(u64(got), np.unique(words))
+    else:
+        assert why == "" and np.array_equal(u64(got), np.unique(words))
+    got2, why2 = ops.region_unique_scattered(dev(words.view(np.int64)), g, id_bits, nids)
+    assert (got2 is None and why2 == "cap") or np.array_equal(u64(got2), np.unique(words))
 
 
 def test_region_unique_reports_overflow_and_unique_pairs_falls_back():
@@ -247,7 +260,7 @@ def test_region_unique_reports_overflow_and_unique_pairs_falls_back():
     lens[1500] = 10
     words = _rows_case(rng, len(lens), lens, 1 << 20, dup=3)
     got = ops.unique_pairs(dev(words[rng.permutation(len(words))].view(np.int64)), (1 << 20) - 1, stats)
-    assert stats["dedup_path"] == "regions-in-lds" and stats["group_bits"] == 8
+    assert stats["dedup_path"].startswith("regions-in-lds") and stats["group_bits"] == 8
     assert np.array_equal(u64(got), np.unique(words))
     # id widths that leave no room for group bits keep the single-i rows
     stats = {}
@@ -546,7 +559,7 @@ def test_full_size_config3_equals_oracle():
     perms = ops.legacy_permutations(P, D, seed=42)
     res = pipeline.query_similarities(off, rows, ops.perm_table(perms, DEV), b, K)
     torch.cuda.synchronize()
-    assert res.stats["bucket_path"] == "partition+lds" and res.stats["dedup_path"] == "regions-in-lds"
+    assert res.stats["bucket_path"] == "partition+lds" and res.stats["dedup_path"] == "regions-in-lds (scattered)"
     assert res.stats["part_bits"] > 8                         # two-step partition
     O.set_threads(16)
     _check_against_oracle(res, off, rows, perms, b, K, nq)
