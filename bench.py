@@ -99,6 +99,10 @@ def algorithmic_bytes_per_step(w):
     ib = max(1, (w["nq_total"] - 1).bit_length())
     g = w.get("group_bits", 0)                    # low bits of i the grouping sort skips (ops.row_group_bits)
     pair_passes = -(-(ib - g) // 8)               # pairs are grouped by i >> g only; rows are finished in LDS
+    group_levels = 0
+    if "scattered" in w.get("dedup_path", ""):    # ... by the histogram-free fixed-region partition: no sort passes over them
+        group_levels = 1 if ib - g <= 8 else 2
+        pair_passes = 0
     sel = w.get("topk", "select") == "select"     # top-K by rank-in-list: only the n reverse words are sorted, on j
     edge_words = -(-ib // 8) * un if sel else -(-(ib + 11) // 8) * 2 * un   # key-passes of the top-K sort
     levels = 1 if w.get("part_bits", 8) <= 8 else 2
@@ -118,6 +122,7 @@ def algorithmic_bytes_per_step(w):
         "row_unique": 8 * em + 8 * un,
         "row_unique_gather": 16 * un,
         "region_unique": 8 * em + 8 * un,             # the same step, one workgroup per 2^g consecutive queries
+        "pair_group": 16 * em * group_levels,         # emitted words dealt into fixed regions: read + written once per level
         "region_gather": 16 * un,
         # the pairs are sorted (i, j) and the kernel keeps / re-finds the first row while i does not change: the second
         # row of every pair + the first row once per RUN of equal i (w["first_rows"]; = un when unknown, i.e. two rows
@@ -319,6 +324,7 @@ def main():
                  P=P, b=b, nnz=nnz, emitted=int(res.stats.get("emitted_pairs", 0)), unique=int(res.pairs.numel()),
                  kept=int(res.src.numel()), sig_bytes=2 if res.sig.dtype == torch.int16 else 4,
                  group_bits=int(res.stats.get("group_bits", 0)), part_bits=int(res.stats.get("part_bits", 8)),
+                 dedup_path=str(res.stats.get("dedup_path", "")),
                  topk=("select" if sharded and world > 1 else res.stats.get("topk", "select")),
                  first_rows=(int((torch.diff(res.pairs >> 32) != 0).sum().item()) + 1) if res.pairs.numel() else 0)
         ab = algorithmic_bytes_per_step(w)
