@@ -46,7 +46,10 @@ LABELS = [
     (r"^topk_select_long_kernel", "topk_select_long"), (r"^center_rows_kernel", "center_rows"),
     (r"^compact_count_kernel<0>", "unique_count"), (r"^compact_fill_kernel<0>", "unique_fill"),
     (r"^compact_count_kernel<1>", "topk_count"), (r"^compact_fill_kernel<1>", "topk_fill"),
-    (r"^score_pairs_kernel", "score_pairs"), (r"^scan_u64_kernel", "scan_blocks"), (r"^synth_kernel", "synth"),
+    (r"^score_pairs_kernel", "score_pairs"), (r"^score_runs_kernel", "score_pairs"), (r"^scan_u64_kernel", "scan_blocks"),
+    (r"^synth_kernel", "synth"), (r"^pair_group_scatter_kernel", "pair_group"), (r"^region_spans_kernel", "region_bounds"),
+    (r"^bucket_big_gather_kernel", "bucket_emit_big"), (r"^user_gram_kernel", "user_gram"),
+    (r"^column_stats_kernel", "user_colstats"), (r"^gram_reduce_kernel", "user_gram_reduce"),
 ]
 
 
