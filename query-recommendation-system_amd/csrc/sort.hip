@@ -690,8 +690,14 @@ __global__ __launch_bounds__(SORT_THREADS, PS_WGS) void part_scatter_atomic_kern
 // high digit of the region id into tmp regions, level 2 deals every tmp region by the low digit into the final regions
 // (region r at r * cap, counts[r] words).  One read + one write of the words per level -- 2.1 -> 1.4 ms for the 190 M words
 // of the 10 M-query workload.  A region that outgrows its cap raises the flag (the caller groups by sorting instead).
+#ifndef QR_PG_IPT
+#define QR_PG_IPT 16
+#endif
+constexpr int PG_IPT = QR_PG_IPT;                 // words per thread of the pair-grouping partition
+constexpr int PG_TILE = SORT_THREADS * PG_IPT;
+constexpr int PG_WGS = PG_IPT <= 16 ? 4 : 2;      // workgroups per CU the staged tile allows
 template <bool LEVEL2>
-__global__ __launch_bounds__(SORT_THREADS, 4) void pair_group_scatter_kernel(
+__global__ __launch_bounds__(SORT_THREADS, PG_WGS) void pair_group_scatter_kernel(
     const uint64_t *__restrict__ in, uint64_t *__restrict__ out, int64_t n_in, int ntiles, int shift, uint32_t dmask,
     uint32_t *__restrict__ cursors, uint32_t cap, uint32_t *__restrict__ overflow, const uint32_t *__restrict__ in_counts,
     uint32_t in_cap) {
@@ -699,26 +705,26 @@ __global__ __launch_bounds__(SORT_THREADS, 4) void pair_group_scatter_kernel(
   __shared__ uint32_t lsum[SORT_THREADS / WAVE];
   __shared__ uint32_t gdelta[RADIX];
   __shared__ uint8_t gok[RADIX];
-  __shared__ uint64_t skey[PS_TILE];
+  __shared__ uint64_t skey[PG_TILE];
   const int tile = LEVEL2 ? (int)blockIdx.x : xcd_tile(blockIdx.x, ntiles), batch = blockIdx.y;
   const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x >> 6;
   const int64_t n = LEVEL2 ? (int64_t)min(in_counts[batch], in_cap) : n_in;
-  const int64_t tbase = (int64_t)tile * PS_TILE;
+  const int64_t tbase = (int64_t)tile * PG_TILE;
   if (tbase >= n) return;  // LEVEL2: the grid covers a full region, this one holds fewer words (uniform)
   cnt[threadIdx.x] = 0;
   __syncthreads();
   const size_t boff = LEVEL2 ? (size_t)batch * in_cap : 0;
-  const int64_t wbase = tbase + (int64_t)w * (WAVE * PS_IPT);
+  const int64_t wbase = tbase + (int64_t)w * (WAVE * PG_IPT);
   const uint32_t nd = dmask + 1u;
-  uint64_t key[PS_IPT];
-  uint32_t dr[PS_IPT];
+  uint64_t key[PG_IPT];
+  uint32_t dr[PG_IPT];
 #pragma unroll
-  for (int k = 0; k < PS_IPT; ++k) {
+  for (int k = 0; k < PG_IPT; ++k) {
     const int64_t idx = wbase + (int64_t)k * WAVE + lane;
     key[k] = idx < n ? in[boff + idx] : 0ull;
   }
 #pragma unroll
-  for (int k = 0; k < PS_IPT; ++k) {
+  for (int k = 0; k < PG_IPT; ++k) {
     const int64_t idx = wbase + (int64_t)k * WAVE + lane;
     const uint32_t d = (uint32_t)(key[k] >> shift) & dmask;
     dr[k] = idx < n ? (d << 16) | atomicAdd(&cnt[d], 1u) : 0xFFFFFFFFu;
@@ -744,7 +750,7 @@ __global__ __launch_bounds__(SORT_THREADS, 4) void pair_group_scatter_kernel(
   }
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < PS_IPT; ++k)
+  for (int k = 0; k < PG_IPT; ++k)
     if (dr[k] != 0xFFFFFFFFu) skey[cnt[dr[k] >> 16] + (dr[k] & 0xFFFFu)] = key[k];
   {
     const int d = threadIdx.x;
@@ -759,7 +765,7 @@ __global__ __launch_bounds__(SORT_THREADS, 4) void pair_group_scatter_kernel(
   for (int k = 0; k < SORT_THREADS / WAVE; ++k) nstaged += lsum[k];
   const size_t obase = (size_t)batch * nd * cap;
 #pragma unroll
-  for (int k = 0; k < PS_IPT; ++k) {
+  for (int k = 0; k < PG_IPT; ++k) {
     const uint32_t p = k * SORT_THREADS + threadIdx.x;
     if (p < nstaged) {
       const uint64_t x = skey[p];
@@ -840,7 +846,7 @@ QRLSH_EXPORT int qrlsh_pair_regions_scatter(const uint64_t *words, int64_t n, in
   }
   if (n == 0) return QRLSH_OK;
   QR_CHECK_ARG(words && regions && (r.ra == 0 || tmp_regions), "qrlsh_pair_regions_scatter: null pointer");
-  const int ntiles = (int)ceil_div64(n, PS_TILE);
+  const int ntiles = (int)ceil_div64(n, PG_TILE);
   const int sh = 32 + group_bits;
   if (r.ra == 0) {
     QR_LAUNCH("pair_group", (pair_group_scatter_kernel<false>), dim3(ntiles, 1), dim3(SORT_THREADS), 0, st, words, regions, n,
@@ -849,7 +855,7 @@ QRLSH_EXPORT int qrlsh_pair_regions_scatter(const uint64_t *words, int64_t n, in
     uint32_t *cur_a = counts + r.nregions;
     QR_LAUNCH("pair_group", (pair_group_scatter_kernel<false>), dim3(ntiles, 1), dim3(SORT_THREADS), 0, st, words, tmp_regions,
               n, ntiles, sh + r.rb, (1u << r.ra) - 1u, cur_a, r.cap_a, overflow_out, (const uint32_t *)nullptr, 0u);
-    QR_LAUNCH("pair_group", (pair_group_scatter_kernel<true>), dim3((unsigned)ceil_div64(r.cap_a, PS_TILE), (unsigned)r.na),
+    QR_LAUNCH("pair_group", (pair_group_scatter_kernel<true>), dim3((unsigned)ceil_div64(r.cap_a, PG_TILE), (unsigned)r.na),
               dim3(SORT_THREADS), 0, st, (const uint64_t *)tmp_regions, regions, (int64_t)0, 0, sh, (1u << r.rb) - 1u, counts,
               r.cap_b, overflow_out, (const uint32_t *)cur_a, r.cap_a);
   }
