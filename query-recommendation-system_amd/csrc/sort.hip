@@ -546,9 +546,12 @@ struct PartPool {
   uint32_t slot_base;           // part slot of this launch's (batch 0, part 0)
 };
 
-constexpr int PS_IPT = 16;  // records per thread of the atomic partition (8, six workgroups per CU: 3.9 ms against 3.4)
+#ifndef QR_PS_IPT
+#define QR_PS_IPT 16
+#endif
+constexpr int PS_IPT = QR_PS_IPT;  // records per thread of the atomic partition (8, six workgroups per CU: 3.9 ms against 3.4)
 constexpr int PS_TILE = SORT_THREADS * PS_IPT;
-constexpr int PS_WGS = 3;   // workgroups per CU the 50 KB LDS image allows
+constexpr int PS_WGS = PS_IPT <= 16 ? 3 : 2;   // workgroups per CU the LDS image (12 B per record) allows
 template <bool LEVEL2>
 __global__ __launch_bounds__(SORT_THREADS, PS_WGS) void part_scatter_atomic_kernel(
     const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint64_t *__restrict__ keys_out,
@@ -691,11 +694,11 @@ __global__ __launch_bounds__(SORT_THREADS, PS_WGS) void part_scatter_atomic_kern
 // (region r at r * cap, counts[r] words).  One read + one write of the words per level -- 2.1 -> 1.4 ms for the 190 M words
 // of the 10 M-query workload.  A region that outgrows its cap raises the flag (the caller groups by sorting instead).
 #ifndef QR_PG_IPT
-#define QR_PG_IPT 16
+#define QR_PG_IPT 32   // 8192-word tiles: runs of 32 - 54 words per (tile, digit); 16: 1.77 ms for the two levels at 10 M, 32: 1.46
 #endif
 constexpr int PG_IPT = QR_PG_IPT;                 // words per thread of the pair-grouping partition
 constexpr int PG_TILE = SORT_THREADS * PG_IPT;
-constexpr int PG_WGS = PG_IPT <= 16 ? 4 : 2;      // workgroups per CU the staged tile allows
+constexpr int PG_WGS = PG_IPT <= 16 ? 4 : PG_IPT <= 40 ? 2 : 1;      // workgroups per CU the staged tile allows
 template <bool LEVEL2>
 __global__ __launch_bounds__(SORT_THREADS, PG_WGS) void pair_group_scatter_kernel(
     const uint64_t *__restrict__ in, uint64_t *__restrict__ out, int64_t n_in, int ntiles, int shift, uint32_t dmask,
