@@ -399,6 +399,7 @@ def region_unique(grouped, group_bits, id_bits, nids):
     return out
 
 
+REGION_MIN_GROUP_BITS = 6               # below: the general sort + unique instead of the region form (see unique_pairs)
 REGION_SCATTER_MAX_BYTES = 48 << 30    # the fixed-region grouping is skipped when its buffers would exceed this
 
 
@@ -453,7 +454,12 @@ def unique_pairs(emitted, nq, stats=None, words_per_query=None, scatter=True):
     wpq = emitted.numel() / max(nq, 1) if words_per_query is None else words_per_query
     g = region_group_bits(ib, nq, wpq)
     pairs = None
-    if g is not None:
+    if g is not None and g < REGION_MIN_GROUP_BITS:
+        # ids of 27 bits and more leave at most 5 group bits: regions of 32 queries, a workgroup per ~2 000 words, three
+        # grouping passes before it -- the plain 7-pass sort + unique is faster there (configs[4], one rank: 4 ms against
+        # 9.6 for 93 M words, 39 against 70.6 for the 897 M it really receives, where the regions would give up anyway)
+        grouped, g = emitted, 0
+    elif g is not None:
         path, why = "regions-in-lds", "cap"
         if scatter:
             pairs, why = region_unique_scattered(emitted, g, ib, nq, wpq)
