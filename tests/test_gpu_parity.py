@@ -717,9 +717,19 @@ def test_sharded_driver_on_gpu_equals_single_gpu(tmp_path, world, mode, backend,
             assert 0 <= int(o["fetched"]) <= (world - 1) * nql   # only rows of the other shards, each once
     K = pipeline.max_candidates(nq)
     off, rows = qrlsh.synth_csr(nq, D, seed=0, device=DEV)
-    res = pipeline.query_similarities(off, rows, ops.perm_table(ops.legacy_permutations(P, D, seed=42), DEV), b, K)
+    perms = ops.legacy_permutations(P, D, seed=42)
+    res = pipeline.query_similarities(off, rows, ops.perm_table(perms, DEV), b, K)
     torch.cuda.synchronize()
     _check_sharded_against(outs, res, nq, world)
+    # ... and the ranks' outputs against the ORACLE directly (not only through the one-GPU result): pairs, scores, top-K
+    ref = O.query_similarities(off.cpu().numpy(), rows.cpu().numpy(), D, P, b, K, 42) if P // b <= 4 else None
+    if ref is not None:
+        pairs = np.concatenate([o["pairs"] for o in outs]).view(np.uint64)
+        order = np.argsort(pairs, kind="stable")
+        assert np.array_equal(pairs[order], ref["pairs"])
+        assert np.array_equal(np.concatenate([o["milli"] for o in outs])[order], ref["milli"])
+        for k in ("src", "dst", "val"):
+            assert np.array_equal(np.concatenate([o[k] for o in outs]), ref[k])
 
 
 def test_rccl_executes_every_collective_shape_at_world_1():
