@@ -1259,6 +1259,151 @@ __global__ __launch_bounds__(THREADS, THREADS >= 1024 ? 8 : 6) void bucket_finis
   }
 }
 
+// The small-part finish with the arrival counters INSIDE the table words (round 4; partitions of 12 bits and more: 10 M
+// queries and up).  Inside a part all words share their top T >= 12 bits (the part number), so a slot needs only the
+// low 52 bits of the word to tell keys apart, and the 12 bits above hold the number of records that found it: a slot is
+// claimed with one CAS (0 -> key52 | 1 << 52: arrival number 0), joined with one returning 64-bit add of 1 << 52 (the old
+// count is the arrival number).  No counter array: the image is 32 KB instead of 48 -- FOUR workgroups per CU instead of
+// three (the kernel is a chain of barrier-separated phases; what hides one workgroup's latency is another workgroup).
+// After the inserts the table is read once (counts -> run starts) and its space re-used: run starts in the lower half,
+// the ids laid out by bucket in the upper half.  Parts of more than 4095 records (the 12-bit count) go to the block
+// kernel like every part beyond the image.
+constexpr int FIN_PK_THREADS = 512, FIN_PK_CAP = 4096, FIN_PK_MAX = 4095;
+__global__ __launch_bounds__(FIN_PK_THREADS, 8) void bucket_finish_packed_kernel(
+    const uint64_t *__restrict__ keys, const uint32_t *__restrict__ ids, int nparts, uint64_t *__restrict__ blk,
+    uint32_t *__restrict__ overflow, uint64_t *__restrict__ out, uint64_t capacity, const uint32_t *__restrict__ counts,
+    uint32_t cap, uint64_t *__restrict__ biglist, unsigned long long *__restrict__ nbig, uint32_t big_max,
+    uint32_t big_base) {
+  constexpr int THREADS = FIN_PK_THREADS, CAP = FIN_PK_CAP, IPT = CAP / THREADS;
+  constexpr unsigned long long KMASK = (1ull << 52) - 1ull, ONE = 1ull << 52;
+  __shared__ unsigned long long gbase;
+  __shared__ __attribute__((aligned(16))) unsigned long long tab[CAP];
+  __shared__ uint32_t wsum[THREADS / WAVE];
+  const int part = blockIdx.x, band = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid >> 6;
+  const size_t bslot = (size_t)band * nparts + part;
+  const uint32_t m = counts[bslot];
+  if (m > (uint32_t)FIN_PK_MAX) {  // uniform: left to the block kernel (in its region, or spilled into the pool)
+    if (tid == 0) {
+      bool listed = false;
+      const unsigned long long at = __hip_atomic_fetch_add(nbig, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (at < (unsigned long long)big_max) {
+        biglist[at] = (uint64_t)(big_base + bslot);
+        listed = true;
+      }
+      if (!listed) atomicOr(overflow, 1u);
+    }
+    return;
+  }
+  if (m == 0) return;
+  const size_t first = bslot * cap;
+  const uint64_t *k = keys + first;
+  const uint32_t *id = ids + first;
+  uint64_t kreg[IPT];
+  uint32_t ireg[IPT];
+#pragma unroll
+  for (int j = 0; j < IPT; ++j) {
+    const uint32_t i = tid + j * THREADS;
+    kreg[j] = i < m ? k[i] : 0ull;
+    ireg[j] = i < m ? id[i] : 0u;
+  }
+#pragma unroll
+  for (int j = 0; j < IPT; ++j) tab[tid + j * THREADS] = 0ull;
+  __syncthreads();
+  uint32_t so[IPT];  // arrival number << 16 | slot; 0xFFFFFFFF = no record
+  uint32_t mine = 0;
+#pragma unroll
+  for (int j = 0; j < IPT; ++j) {
+    so[j] = 0xFFFFFFFFu;
+    if (tid + j * THREADS < (int)m) {
+      const unsigned long long k52 = kreg[j] & KMASK;
+      uint32_t slot = fin_home<CAP>(kreg[j]);
+      uint32_t o;
+      for (;;) {  // at most 4095 records for 4096 slots: a free one always turns up
+        const unsigned long long old = atomicCAS(&tab[slot], 0ull, k52 | ONE);
+        if (old == 0ull) {
+          o = 0;
+          break;
+        }
+        if ((old & KMASK) == k52) {
+          o = (uint32_t)(atomicAdd(&tab[slot], ONE) >> 52);
+          break;
+        }
+        slot = slot + 1 == (uint32_t)CAP ? 0u : slot + 1;
+      }
+      so[j] = o << 16 | slot;
+      mine += o;
+    }
+  }
+  uint32_t inc = mine;
+#pragma unroll
+  for (int d = 1; d < WAVE; d <<= 1) {
+    const uint32_t o = __shfl_up(inc, d, WAVE);
+    if (lane >= d) inc += o;
+  }
+  if (lane == WAVE - 1) wsum[w] = inc;
+  __syncthreads();  // also: every insert is over
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < THREADS / WAVE; ++i) {
+    const uint32_t x = wsum[i];
+    if (i < w) base += x;
+    tot += x;
+  }
+  if (tot == 0) return;  // uniform
+  if (tid == 0)
+    gbase = __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(blk), (unsigned long long)tot, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+  const uint32_t pos0 = base + inc - mine;
+  uint32_t *rs = reinterpret_cast<uint32_t *>(tab);        // run starts: lower half of the table's space ...
+  uint32_t *grp = rs + CAP;                                // ... ids by bucket: upper half
+  {
+    const uint32_t b0 = tid * IPT;
+    uint32_t v[IPT], sum = 0;
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) {
+      v[q] = (uint32_t)(tab[b0 + q] >> 52);
+      sum += v[q];
+    }
+    uint32_t sinc = sum;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+      const uint32_t o = __shfl_up(sinc, d, WAVE);
+      if (lane >= d) sinc += o;
+    }
+    __syncthreads();  // wsum was read by everyone above; every table word has been read
+    if (lane == WAVE - 1) wsum[w] = sinc;
+    __syncthreads();
+    uint32_t run = sinc - sum;
+#pragma unroll
+    for (int i = 0; i < THREADS / WAVE; ++i)
+      if (i < w) run += wsum[i];
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) {
+      rs[b0 + q] = run;
+      run += v[q];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < IPT; ++j)
+    if (so[j] != 0xFFFFFFFFu) grp[rs[so[j] & 0xFFFFu] + (so[j] >> 16)] = ireg[j];
+  __syncthreads();
+  {
+    const uint64_t obase = (uint64_t)gbase;
+    if (obase + tot > capacity) return;  // uniform: counted, not written
+    uint64_t *dst = out + obase;
+    uint32_t pos = pos0;
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+      const bool rec = so[j] != 0xFFFFFFFFu;
+      const uint32_t o = rec ? so[j] >> 16 : 0u;
+      emit_run(dst, pos, ireg[j], grp, rec ? rs[so[j] & 0xFFFFu] : 0u, o);
+      pos += o;
+    }
+  }
+}
+
 // Parts the kernel above listed (more records than its LDS image): worked in BLOCKS of
 // FIN_CAP records by workgroups that walk the device-side list (fixed grid; nothing is read back to size the
 // launch).  Block bi is finished exactly like a small part (hash table on the full word, arrival numbers, bucket
@@ -1554,6 +1699,12 @@ __global__ __launch_bounds__(FIN_THREADS) void bucket_finish_big_kernel(
     }
   }
 }
+
+// the packed-counter form of the small-part finish (QRLSH_FIN_PACKED=0: the separate-counter form; an A/B knob)
+static int g_fin_packed = [] {
+  const char *e = getenv("QRLSH_FIN_PACKED");
+  return !(e && e[0] == '0') ? 1 : 0;
+}();
 
 // records a listed part may hold (qrlsh_set_big_part_limit; default and maximum: FIN_BIG_BLOCKS images)
 static uint32_t g_big_limit = (uint32_t)FIN_BIG_BLOCKS * FIN_CAP;
@@ -1891,7 +2042,12 @@ QRLSH_EXPORT int qrlsh_bucket_pairs_emit_chunked(const uint64_t *keys, int64_t k
       // second group's partition then starts beside the first group's finish, and the two streams stay half a
       // group out of step
       if (gi == 0 && b > per) aux = qr_aux_fork(st);
-      if (small_parts)
+      if (small_parts && T >= 12 && g_fin_packed)
+        QR_LAUNCH("bucket_emit", bucket_finish_packed_kernel, dim3(nparts, nb), dim3(FIN_PK_THREADS), 0, s,
+                  (const uint64_t *)part_keys + ((size_t)g0 << T) * cap2, (const uint32_t *)part_ids + ((size_t)g0 << T) * cap2,
+                  nparts, total_overflow_out, ovf, pairs_out, capacity, (const uint32_t *)cur2 + ((size_t)g0 << T), cap2, biglist,
+                  nbig, big_max, (uint32_t)((size_t)g0 << T));
+      else if (small_parts)
         QR_LAUNCH("bucket_emit", (bucket_finish_kernel<FIN_EMIT, FIN_SMALL_THREADS, FIN_SMALL_CAP>), dim3(nparts, nb),
                   dim3(FIN_SMALL_THREADS), 0, s, (const uint64_t *)part_keys + ((size_t)g0 << T) * cap2,
                   (const uint32_t *)part_ids + ((size_t)g0 << T) * cap2, nq, (const uint32_t *)nullptr, nparts, ekx,
