@@ -112,7 +112,7 @@ constexpr int GR_RS = GR_T + 1;    // row stride (doubles) of the [k][user] imag
 // 256 threads = 4 waves, wave w owns the 64 x 64 quadrant (w >> 1, w & 1) as 4 x 4 MFMA tiles of 16 x 16.
 // f64 MFMA operand maps: A[row = lane & 15][k = lane >> 4], B[k = lane >> 4][col = lane & 15]; D: col = lane & 15,
 // row = (lane >> 4) + 4 * reg.
-__global__ __launch_bounds__(256, 1) void user_gram_kernel(const int32_t *__restrict__ ratings, int64_t nu, int64_t nq,
+__global__ __launch_bounds__(256, 2) void user_gram_kernel(const int32_t *__restrict__ ratings, int64_t nu, int64_t nq,
                                                            const double *__restrict__ mean,
                                                            const double *__restrict__ inv_scale, int64_t slice_cols,
                                                            int ntile, double *__restrict__ partial) {
@@ -135,17 +135,40 @@ __global__ __launch_bounds__(256, 1) void user_gram_kernel(const int32_t *__rest
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[m][n] = f64x4{0.0, 0.0, 0.0, 0.0};
   const int kk = t & (GR_K - 1), r0 = t >> 5;   // staging: thread = (column kk of the step, rows r0, r0 + 8, ...)
-  for (int64_t c0 = c_lo; c0 < c_hi; c0 += GR_K) {
+  constexpr int RPT = GR_T / (256 / GR_K);      // rows a thread stages per step (16)
+  // the ratings of the NEXT step are requested before the current step's MFMAs and standardized into LDS after them:
+  // the trip to memory runs behind 128 matrix instructions per wave instead of in front of them
+  int32_t xa[RPT], xb[RPT];
+  double mu = 0.0, is = 0.0;
+  // 32-bit element offsets from the two tile bases (128 rows x nq columns < 2^32: the host checks nq <= 2^24)
+  const int32_t *ta = ratings + (size_t)i0 * nq, *tb = ratings + (size_t)j0 * nq;
+  const uint32_t rstep = (uint32_t)(256 / GR_K) * (uint32_t)nq, rbase = (uint32_t)r0 * (uint32_t)nq;
+  auto request = [&](int64_t c0) {
     const int64_t col = c0 + kk;
     const bool cok = col < c_hi;
-    const double mu = cok ? mean[col] : 0.0, is = cok ? inv_scale[col] : 0.0;
-#pragma unroll 4
-    for (int r = r0; r < GR_T; r += 256 / GR_K) {
-      const int64_t ui = i0 + r, uj = j0 + r;
-      za[kk][r] = (cok && ui < nu) ? ((double)ratings[ui * nq + col] - mu) * is : 0.0;
-      if (!diag) zb[kk][r] = (cok && uj < nu) ? ((double)ratings[uj * nq + col] - mu) * is : 0.0;
+    mu = cok ? mean[col] : 0.0;
+    is = cok ? inv_scale[col] : 0.0;   // (0 for columns beyond the slice: they stage zeros)
+    const uint32_t off = rbase + (uint32_t)col;
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+      const int r = r0 + q * (256 / GR_K);
+      xa[q] = (cok && i0 + r < nu) ? ta[off + (uint32_t)q * rstep] : 0;
+      xb[q] = (!diag && cok && j0 + r < nu) ? tb[off + (uint32_t)q * rstep] : 0;
+    }
+  };
+  request(c_lo);
+  for (int64_t c0 = c_lo; c0 < c_hi; c0 += GR_K) {
+    {
+      const bool cok = c0 + kk < c_hi;
+#pragma unroll
+      for (int q = 0; q < RPT; ++q) {
+        const int r = r0 + q * (256 / GR_K);
+        za[kk][r] = (cok && i0 + r < nu) ? ((double)xa[q] - mu) * is : 0.0;
+        if (!diag) zb[kk][r] = (cok && j0 + r < nu) ? ((double)xb[q] - mu) * is : 0.0;
+      }
     }
     __syncthreads();
+    if (c0 + GR_K < c_hi) request(c0 + GR_K);
     const double (*zbb)[GR_RS] = diag ? za : zb;
 #pragma unroll
     for (int ks = 0; ks < GR_K / 4; ++ks) {
@@ -194,7 +217,8 @@ QRLSH_EXPORT size_t qrlsh_user_gram_workspace_bytes(int64_t nu, int64_t nq) {
 
 QRLSH_EXPORT int qrlsh_user_gram(const int32_t *ratings, int64_t nu, int64_t nq, double *mean_out, double *inv_scale_out,
                                  double *gram_out, void *workspace, size_t workspace_bytes, void *stream) {
-  QR_CHECK_ARG(nu > 0 && nq > 0 && nu < (1ll << 20), "qrlsh_user_gram: bad sizes nu=%lld nq=%lld", (long long)nu, (long long)nq);
+  QR_CHECK_ARG(nu > 0 && nq > 0 && nu < (1ll << 20) && nq <= (1ll << 24), "qrlsh_user_gram: bad sizes nu=%lld nq=%lld",
+               (long long)nu, (long long)nq);
   QR_CHECK_ARG(ratings && mean_out && inv_scale_out && gram_out && workspace, "qrlsh_user_gram: null pointer");
   if (workspace_bytes < qrlsh_user_gram_workspace_bytes(nu, nq)) {
     qrlsh_set_error("qrlsh_user_gram: workspace %zu < %zu bytes", workspace_bytes, qrlsh_user_gram_workspace_bytes(nu, nq));

@@ -27,12 +27,15 @@ CASES = [
     (700_000, 100_000, 128, 32, 8, 16.0, 0.15),      # int32 table / signatures
     (500_000, 32768, 100, 20, 8, 16.0, 0.15),        # wide bands r = 5 (hashed ids + verification)
     (200_000, 32768, 96, 32, 8, 16.0, 0.15),         # r = 3
+    (6_000_000, 32768, 128, 32, 64, 16.0, 0.05),     # T = 11: small-part finish (separate counters), buckets of 64, spills
+    (12_000_000, 32768, 128, 32, 8, 16.0, 0.15),     # T = 12: packed-counter finish, scattered pair regions, run-form scoring
+    (9_000_000, 32768, 256, 64, 16, 12.0, 0.10),     # the same with 256-value rows
 ]
 
 
 def main():
     quick = "--quick" in sys.argv
-    O.set_threads(16)
+    O.set_threads(int(os.environ.get('QRLSH_TEST_THREADS', '16')))
     bad = 0
     for (nq, D, P, b, cl, mean, pr) in (CASES[:3] if quick else CASES):
         K = pipeline.max_candidates(nq)
