@@ -34,7 +34,7 @@ LABELS = [
     (r"^sort_scatter_kernel<\d+, false", "sort_scatter_k"), (r"^sort_scatter_kernel<\d+, true", "sort_scatter_kv"),
     (r"^bucket_finish_kernel<0[,>]", "bucket_count"), (r"^bucket_finish_kernel<1[,>]", "bucket_fill"),
     (r"^bucket_finish_kernel<2[,>]", "bucket_emit"), (r"^bucket_bounds_kernel", "bucket_bounds"),
-    (r"^bucket_finish_big_kernel", "bucket_emit_big"),
+    (r"^bucket_finish_big_kernel", "bucket_emit_big"), (r"^bucket_finish_packed_kernel", "bucket_emit"),
     (r"^pairs_count_kernel", "pairs_count"), (r"^pairs_fill_kernel", "pairs_fill"),
     (r"^row_unique_kernel", "row_unique"), (r"^row_unique_gather_kernel", "row_unique_gather"),
     (r"^sort_scatter_staged_kernel", "sort_scatter_k"), (r"^part_scatter_staged_kernel", "sort_scatter_kv"),
