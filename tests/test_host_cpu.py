@@ -91,6 +91,21 @@ def test_host_size_rules():
     assert lib.qrlsh_bucket_part_words(100_000_000, 8, 15) == 8 * 32768 * 6144 + 8 * 100_000_000 // 16
     assert lib.qrlsh_bucket_part_words(100_000_000, 8, 15) < 2.1 * 8 * 100_000_000
     assert lib.qrlsh_bucket_part_words(1 << 25, 2, 9) == 2 * (1 << 25)          # ids past 24 bits: sort-based layout
+    # fixed regions of the histogram-free pair grouping: 10 M ids in regions of 256 queries = 39 063 regions, dealt by two
+    # levels of 8 bits (153 coarse digits x 256); capacity 3 x the mean + 4096, rounded to 64 words
+    n, nids = 190_012_232, 10_000_000
+    assert lib.qrlsh_pair_regions_count(n, nids, 8, 0.0) == 153 * 256
+    cap = lib.qrlsh_pair_regions_cap(n, nids, 8, 0.0)
+    assert cap % 64 == 0 and 3 * (n // 39063) + 4096 <= cap < 3 * (n // 39063) + 4096 + 128
+    assert lib.qrlsh_pair_regions_words(n, nids, 8, 0.0) == 153 * 256 * cap
+    assert lib.qrlsh_pair_regions_tmp_words(n, nids, 8, 0.0) > 2 * n            # 153 coarse regions of 2.5 x the mean
+    assert lib.qrlsh_pair_regions_cap(n, nids, 8, 100.0) > cap                    # a caller's density hint can only enlarge them
+    assert lib.qrlsh_pair_regions_tmp_words(1000, 200, 7, 0.0) == 0               # up to 256 regions: one level
+    assert lib.qrlsh_pair_regions_count(1000, 200, 7, 0.0) == 2
+    assert lib.qrlsh_pair_regions_words(10 ** 9, 100_000_000, 5, 0.0) == 0        # more than 65536 regions: not served
+    assert lib.qrlsh_set_big_part_limit(0) == 16 * 6144 and lib.qrlsh_set_big_part_limit(5000) == 16 * 6144
+    assert lib.qrlsh_set_big_part_limit(10 ** 9) == 5000 and lib.qrlsh_set_big_part_limit(0) == 16 * 6144
+    assert lib.qrlsh_user_gram_workspace_bytes(2000, 100_000) == 16 * 2000 * 2000 * 8
     assert lib.qrlsh_row_unique_workspace_bytes(0) > 0
     assert lib.qrlsh_row_unique_workspace_bytes(10 ** 8) > lib.qrlsh_row_unique_workspace_bytes(10 ** 6)
 
