@@ -423,14 +423,19 @@ def region_unique_scattered(emitted, group_bits, id_bits, nids, words_per_query=
         return None, "cap"          # (words == 0: more than 65536 regions -- two levels of 256 digits do not reach)
     cap = lib.qrlsh_pair_regions_cap(n, nids, group_bits, wpq)
     nreg = lib.qrlsh_pair_regions_count(n, nids, group_bits, wpq)
-    regions = torch.empty((words,), dtype=torch.int64, device=dev)
-    tmpr = torch.empty((twords,), dtype=torch.int64, device=dev) if twords else None
+    try:      # fixed regions trade memory for passes: when the device is short of it, group by sorting instead
+        regions = torch.empty((words,), dtype=torch.int64, device=dev)
+        tmpr = torch.empty((twords,), dtype=torch.int64, device=dev) if twords else None
+        tmp = torch.empty_like(regions)
+    except torch.cuda.OutOfMemoryError:
+        regions = tmpr = tmp = None
+        torch.cuda.empty_cache()
+        return None, "cap"
     counts = torch.empty((nreg + 256,), dtype=torch.int32, device=dev)
     ovf = torch.empty((1,), dtype=torch.int32, device=dev)
     _lib.check(lib.qrlsh_pair_regions_scatter(_ptr(emitted), n, int(group_bits), int(nids), wpq, _ptr(tmpr), _ptr(regions),
                                               _ptr(counts), _ptr(ovf), _stream()))
     del tmpr
-    tmp = torch.empty_like(regions)
     ws = _ws(lib.qrlsh_region_unique_workspace_bytes(nids, group_bits), dev)
     tot = torch.empty(2, dtype=torch.int64, device=dev)
     _lib.check(lib.qrlsh_region_unique_count_regions(_ptr(regions), _ptr(counts), cap, n, int(group_bits), int(id_bits),
