@@ -31,13 +31,32 @@ def planted_keys(rng, nq, b, groups):
     return keys
 
 
-def same_part_keys(rng, nq, T, sizes):
-    """one band whose popular keys all hash into ONE part of the T-bit partition (mix64's top bits)"""
+def np_mix64(z):
+    z = z.astype(np.uint64)
+    with np.errstate(over="ignore"):
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def same_part_keys(rng, nq, T, sizes, fill_to=None):
+    """one band whose popular keys all hash into ONE part of the T-bit partition (mix64's top bits).
+    fill_to: instead of sizes, ONE key with exactly as many copies as bring that part to fill_to records."""
     lib = _lib.load()
     keys = rng.integers(1, 1 << 62, size=(1, nq), dtype=np.int64)
     want = None
     perm = rng.permutation(nq)
     at = 0
+    if fill_to is not None:
+        k = int(rng.integers(1, 1 << 62))
+        want = lib.qrlsh_mix64_host(k) >> (64 - T)
+        parts = (np_mix64(keys[0].view(np.uint64)) >> np.uint64(64 - T)).astype(np.int64)
+        inside = np.flatnonzero(parts == want)
+        outside = np.flatnonzero(parts != want)
+        size = fill_to - len(inside)
+        assert size > 1
+        keys[0, outside[:size]] = k          # background records of the part stay, `size` records from elsewhere join it
+        return keys
     for size in sizes:
         while True:
             k = int(rng.integers(1, 1 << 62))
@@ -84,9 +103,13 @@ def main():
         bad += not check("T=12, five popular keys in one part", same_part_keys(rng, 12_000_000, 12, [3000, 2500, 900, 5000, 1200]))
         bad += not check("T=11, four popular keys in one part", same_part_keys(rng, 6_000_000, 11, [2000, 2100, 1500, 7000]))
         bad += not check("T=8, popular keys in one part", same_part_keys(rng, 1_000_000, 8, [4000, 2500, 800]))
-        # a part filled to exactly the image (4096) / one short of it / one beyond, T = 12: background of the part ~2930
-        for extra in (1100, 1160, 1166, 1167, 1168, 1200):
-            bad += not check("T=12, one key of %d copies" % extra, same_part_keys(rng, 12_000_000, 12, [extra]))
+        # a part filled to exactly the image / one short of it / one beyond (the background records of the part are counted)
+        for fill in (4094, 4095, 4096, 4097, 6143, 6144, 6145):
+            bad += not check("T=12, a part of exactly %d records" % fill, same_part_keys(rng, 12_000_000, 12, None, fill_to=fill))
+        for fill in (4095, 4096, 4097):
+            bad += not check("T=11, a part of exactly %d records" % fill, same_part_keys(rng, 6_000_000, 11, None, fill_to=fill))
+        for fill in (6143, 6144, 6145):
+            bad += not check("T=8, a part of exactly %d records" % fill, same_part_keys(rng, 1_000_000, 8, None, fill_to=fill))
     print("stress: %d failing case(s)" % bad)
     return 1 if bad else 0
 
