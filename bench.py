@@ -390,7 +390,12 @@ def main():
         if world == 1 and not sharded and not args.no_secondary:
             del res
             torch.cuda.empty_cache()
-            secondary = secondary_figures(dev, table, P, b, D)
+            try:       # the secondary figures must never cost the run its headline line
+                secondary = secondary_figures(dev, table, P, b, D)
+            except Exception as exc:  # noqa: BLE001  (reported in the line itself)
+                import traceback
+                sys.stderr.write("bench.py: secondary figures failed:\n" + traceback.format_exc())
+                secondary = {"secondary_error": "%s: %s" % (type(exc).__name__, exc)}
             res = None
 
         out = {
